@@ -1,0 +1,200 @@
+/*
+ * ctunet_hip.h — C ABI of libctunet_hip.so: the MI355X (gfx950) kernels under the Hybrid-CTUNet hot path.
+ *
+ * The reference (shouwangzhe134/Hybrid-CTUNet) has NO FFI: its boundary is the Python nn.Module API
+ * (networks/hybrid_CTUNet.py:694-1036).  Every FLOP there is dispatched through ATen leaf ops; this header
+ * declares the native entry points that replace those leaf-op families, one group per row of SURVEY.md
+ * section 2.2 (K1..K15).  Each declaration cites the reference call sites it stands in for.  The host-side
+ * mirror (hybrid-ctunet_amd/networks/*.py) binds these with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  All pointers are DEVICE pointers unless noted.
+ *   - activations are channels-last ("NDHWC"): a volume tensor is a row-major [rows = B*D*H*W][C] matrix.
+ *   - dtype selects the activation/packed-weight element type: CTU_F32 (parity mode, f32-input MFMA) or
+ *     CTU_BF16 (bf16 operands, fp32 accumulate).  Statistics, losses, master weights and weight
+ *     gradients are always fp32.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), allocates nothing and keeps no
+ *     global state; workspaces are passed in.  Graph-capture safe.
+ *   - return value: CTU_OK or an error code; ctu_last_error() gives a thread-local message.
+ */
+#ifndef CTUNET_HIP_H
+#define CTUNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTU_OK 0
+#define CTU_ERR_ARG 1     /* unsupported shape / null pointer / misaligned channel count */
+#define CTU_ERR_LAUNCH 2  /* hipGetLastError() after launch was not hipSuccess */
+
+typedef enum { CTU_F32 = 0, CTU_BF16 = 1 } ctu_dtype;
+typedef void* ctu_stream_t; /* hipStream_t */
+
+int ctu_abi_version(void);
+const char* ctu_last_error(void);
+
+/* Geometry of an implicit GEMM over a channels-last volume.
+ * Row space  : M = B*Do*Ho*Wo rows (one per voxel of the Do x Ho x Wo grid).
+ * Gather grid: B*Di*Hi*Wi voxels with C1 (+C2, a second tensor concatenated along channels) channels.
+ * For row (b,od,oh,ow) and tap (td,th,tw) the gathered voxel is
+ *   mode 0:  i = o*s - p + t                      (forward convolution, nn.Conv3d)
+ *   mode 1:  i = (o + p - t) / s  if divisible    (data gradient of a strided convolution / transposed gather)
+ * and contributes zero when out of range.  A plain GEMM is kd=kh=kw=1, s=1, p=0, Di=Do=M, others 1. */
+typedef struct ctu_geom {
+  int32_t B, Di, Hi, Wi;
+  int32_t Do, Ho, Wo;
+  int32_t C1, C2;
+  int32_t N;
+  int32_t kd, kh, kw;
+  int32_t sd, sh, sw;
+  int32_t pd, ph, pw;
+  int32_t mode;
+} ctu_geom;
+
+/* Epilogue of ctu_igemm_nt. */
+typedef struct ctu_epilogue {
+  const float* bias;    /* [N] fp32 or NULL                                  */
+  const void* residual; /* [M][ldc] same dtype as out, added after act, or NULL */
+  int32_t act;          /* 0 none, 1 exact-erf GELU                           */
+  int32_t ldc;          /* leading dimension (elements) of out                */
+  void* out2;           /* second destination for columns >= n_split, or NULL  */
+  int32_t n_split;      /* 0 = unused; multiple of 8                           */
+  int32_t ldc2;
+  /* transposed-convolution scatter (kernel == stride, nn.ConvTranspose3d at hybrid_CTUNet.py:177-185):
+   * column n = tap*n_per_tap + co ; row m = (b,d,h,w) of the sc_D x sc_H x sc_W input grid is written to
+   * output voxel (b, d*kd+td, h*kh+th, w*kw+tw), channel co.  scatter = 0 disables. */
+  int32_t scatter;
+  int32_t n_per_tap;
+  int32_t sc_D, sc_H, sc_W, sc_kd, sc_kh, sc_kw;
+} ctu_epilogue;
+
+/* K1/K3/K5/K2/K4 forward and data-gradient:  out[m][n] = sum_tap sum_c A[gather(m,tap)][c] * W[tap][n][c]
+ * (+bias, GELU, +residual).  W is the packed [taps][N][C1+C2] panel in `dtype` (see ctu_permute3).
+ * Replaces nn.Conv3d 3x3x3/1x1x1/strided (resnet.py:96-100,150-155,197; hybrid_CTUNet.py:57-83), nn.Linear
+ * (vit.py:36,39,59,62,117; hybrid_CTUNet.py:402,457,465,519,522,632-633,641,679), nn.ConvTranspose3d
+ * (hybrid_CTUNet.py:177-185,232-240,286-294) and their input gradients.  C1,C2,N multiples of 8. */
+int ctu_igemm_nt(ctu_dtype dtype, const void* a1, const void* a2, const void* w, void* out,
+                 const ctu_geom* g, const ctu_epilogue* ep, ctu_stream_t stream);
+
+/* Weight gradient:  dw[tap][n][c] += sum_m P[m][n] * Q[gather(m,tap)][c]   (fp32 atomics into a zeroed panel).
+ * P has g->N columns (leading dim ldp) over the row space, Q1/Q2 are the gathered tensors (C1/C2 channels). */
+int ctu_igemm_tn(ctu_dtype dtype, const void* p, int32_t ldp, const void* q1, const void* q2, float* dw,
+                 const ctu_geom* g, ctu_stream_t stream);
+
+/* Cin == 1 convolutions (vit_encoder0.conv1 1->64 3x3x3, hybrid_CTUNet.py:57-65; ResNet stem 7x7x7 s(2,2,1),
+ * resnet.py:150-155).  x: [B][Di][Hi][Wi] ; w: fp32 [taps][N] ; out: [M][N].  kernel 3x3x3 or 7x7x7 only. */
+int ctu_conv_cin1_fwd(ctu_dtype dtype, const void* x, const float* w, void* out, const ctu_geom* g,
+                      ctu_stream_t stream);
+int ctu_conv_cin1_wgrad(ctu_dtype dtype, const void* x, const void* dy, float* dw, const ctu_geom* g,
+                        ctu_stream_t stream);
+
+/* Strided 3-index permute + cast: dst[i0*d0 + i1*d1 + i2*d2] = (dst_dtype) src[i0*s0 + i1*s1 + i2*s2].
+ * src is fp32 (master weights / packed fp32 gradients).  Used to pack weights into [taps][N][K] panels and
+ * to unpack panel gradients back into the nn.Module's parameter layout (accumulate=1 adds into dst, fp32). */
+int ctu_permute3(const float* src, void* dst, ctu_dtype dst_dtype, int64_t n0, int64_t n1, int64_t n2,
+                 int64_t s0, int64_t s1, int64_t s2, int64_t d0, int64_t d1, int64_t d2, int32_t accumulate,
+                 ctu_stream_t stream);
+/* column sums (bias gradients): out[n] += sum_m x[m][n], x is [M][ld] */
+int ctu_colsum(ctu_dtype dtype, const void* x, int64_t M, int32_t N, int32_t ld, float* out,
+               ctu_stream_t stream);
+
+/* K6/K7 InstanceNorm3d (eps 1e-5, no affine) fused with residual add and LeakyReLU(0.01)
+ * (resnet.py:97-124,156-157,198; hybrid_CTUNet.py:84-104).  x: [B][S][C]; stats: fp32 [B][C][2] = (sum, sumsq),
+ * zeroed by the caller before ctu_in_stats.  y = act((x-mean)*rstd + residual). */
+int ctu_in_stats(ctu_dtype dtype, const void* x, int32_t B, int64_t S, int32_t C, float* stats,
+                 ctu_stream_t stream);
+int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, const void* residual, void* y, int32_t B,
+                 int64_t S, int32_t C, int32_t act, ctu_stream_t stream);
+/* backward: g = dy * act'(y); sums[b][c] = (sum g, sum g*xhat) (zeroed by caller);
+ * dx = rstd*(g - s1/S - xhat*s2/S); dres = g when dres != NULL. */
+int ctu_in_bwd_reduce(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
+                      float* sums, int32_t B, int64_t S, int32_t C, int32_t act, ctu_stream_t stream);
+int ctu_in_bwd_apply(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
+                     const float* sums, void* dx, void* dres, int32_t B, int64_t S, int32_t C, int32_t act,
+                     ctu_stream_t stream);
+
+/* K8 LayerNorm (eps 1e-5, affine) (vit.py:35,55,116,118; hybrid_CTUNet.py:456,518,630-631).
+ * x,y: [rows][dim]; mean_rstd: fp32 [rows][2]; dgamma/dbeta: fp32 [dim], accumulated (atomics). */
+int ctu_layernorm_fwd(ctu_dtype dtype, const void* x, const float* gamma, const float* beta, void* y,
+                      float* mean_rstd, int64_t rows, int32_t dim, ctu_stream_t stream);
+int ctu_layernorm_bwd(ctu_dtype dtype, const void* dy, const void* x, const float* gamma, const float* mean_rstd,
+                      void* dx, float* dgamma, float* dbeta, int64_t rows, int32_t dim, ctu_stream_t stream);
+
+/* K12 GELU (exact erf) and plain adds (vit.py:37; hybrid_CTUNet.py:520; Residual :434-440). n multiple of 8. */
+int ctu_gelu_fwd(ctu_dtype dtype, const void* x, void* y, int64_t n, ctu_stream_t stream);
+int ctu_gelu_bwd(ctu_dtype dtype, const void* dy, const void* x, void* dx, int64_t n, ctu_stream_t stream);
+int ctu_add(ctu_dtype dtype, const void* a, const void* b, void* y, int64_t n, ctu_stream_t stream);
+/* y[r][c] = a[r][c] + bcast[r % period][c]  (vit.py:133 pos_embedding); fp32 bcast */
+int ctu_add_bcast(ctu_dtype dtype, const void* a, const float* bcast, void* y, int64_t rows, int32_t cols,
+                  int64_t period, ctu_stream_t stream);
+
+/* K9/K10 multi-head self-attention core on a fused qkv matrix [rows][3*heads*dh] (q|k|v, heads inside each).
+ * Token partition (which rows form one attention group of ntok tokens):
+ *   part 0: contiguous: group g = rows [g*ntok, (g+1)*ntok)                      (vit.py:66-78)
+ *   part 1: block windows of win^3 voxels of a [B][D][H][W] grid  '(h h1)'       (hybrid_CTUNet.py:559)
+ *   part 2: grid  windows (dilated, stride D/win)                 '(h1 h)'       (hybrid_CTUNet.py:564)
+ * s = scale*(q.k) + bias_table[relidx(i,j)][head] (bias_table NULL for ViT; [ (2win-1)^3 ][heads] fp32,
+ * hybrid_CTUNet.py:470-500); softmax over keys; out = P.v written to out[rows][heads*dh].
+ * lse: fp32 [groups*heads][ntok] (log-sum-exp, saved for backward). */
+typedef struct ctu_attn_geom {
+  int32_t part;        /* 0,1,2 */
+  int32_t B, D, H, W;  /* volume grid (part 1,2); for part 0: B groups, D*H*W = ntok */
+  int32_t win;         /* window edge (6) for part 1,2 */
+  int32_t heads, dh;   /* dh in {32, 64} */
+  float scale;
+} ctu_attn_geom;
+int ctu_attn_fwd(ctu_dtype dtype, const void* qkv, const float* bias_table, void* out, float* lse,
+                 const ctu_attn_geom* g, ctu_stream_t stream);
+/* backward: dqkv [rows][3*heads*dh]; dbias fp32 accumulated (atomics) or NULL. */
+int ctu_attn_bwd(ctu_dtype dtype, const void* qkv, const float* bias_table, const void* out, const void* dout,
+                 const float* lse, void* dqkv, float* dbias, const ctu_attn_geom* g, ctu_stream_t stream);
+
+/* K11 binary cross-weight fusion core (hybrid_CTUNet.py:651-665): per token, per head of 32 channels:
+ * a1 = sigmoid(scale*(<q2,k1> - <q1,k2>)); out = a1*v1 + (1-a1)*v2.  qkv1,qkv2: [rows][3*C]; out: [rows][C]. */
+int ctu_pwa_fwd(ctu_dtype dtype, const void* qkv1, const void* qkv2, void* out, int64_t rows, int32_t C,
+                float scale, ctu_stream_t stream);
+int ctu_pwa_bwd(ctu_dtype dtype, const void* qkv1, const void* qkv2, const void* dout, void* dqkv1, void* dqkv2,
+                int64_t rows, int32_t C, float scale, ctu_stream_t stream);
+
+/* K13 layout ops.  patchify: x [B][H][W][F] -> tokens [B][(H/p1)(W/p2)(F/p3)][p1*p2*p3]   (vit.py:115, c=1).
+ * pixel shuffle: x [B][D][H][W][c*p1*p2*p3] -> y [B][D*p1][H*p2][W*p3][c]  (hybrid_CTUNet.py:420-428);
+ * inverse = 1 applies the inverse map (its gradient). */
+int ctu_patchify(ctu_dtype dtype, const void* x, void* tokens, int32_t B, int32_t H, int32_t W, int32_t F,
+                 int32_t p1, int32_t p2, int32_t p3, ctu_stream_t stream);
+int ctu_pixel_shuffle(ctu_dtype dtype, const void* x, void* y, int32_t B, int32_t D, int32_t H, int32_t W,
+                      int32_t c, int32_t p1, int32_t p2, int32_t p3, int32_t inverse, ctu_stream_t stream);
+
+/* K14 DiceCE (MONAI DiceCELoss(to_onehot_y, softmax, squared_pred, smooth_nr=0, smooth_dr), main_CTUNet.py:156-158)
+ * with the nearest-neighbour deep-supervision target map of trainer_CTUNet.py:93-94 fused in.
+ * logits: [B][D][H][W][ldl] (first n_cls columns valid); labels: fp32 class ids [B][LD][LH][LW] (full res);
+ * idx_d/h/w: int32 source index per logit coordinate (length D,H,W).  acc: fp32 [B][n_cls][3] + [1]
+ * (sum p*y, sum p^2, sum y, then CE sum at acc[B*n_cls*3]), zeroed by the caller.
+ * loss_out[0] += weight * (dice + ce)  (device scalar, fp32). */
+int ctu_dicece_fwd(ctu_dtype dtype, const void* logits, int32_t ldl, const float* labels, const int32_t* idx_d,
+                   const int32_t* idx_h, const int32_t* idx_w, int32_t B, int32_t D, int32_t H, int32_t W,
+                   int32_t LD, int32_t LH, int32_t LW, int32_t n_cls, float* acc, ctu_stream_t stream);
+int ctu_dicece_finalize(const float* acc, int32_t B, int32_t n_cls, int64_t S, float smooth_nr, float smooth_dr,
+                        float weight, float* loss_out, ctu_stream_t stream);
+/* dlogits[..][ldl] = weight * gscale[0] * d(dice+ce)/dlogits (pad columns written as 0). gscale: device fp32 or NULL (=1). */
+int ctu_dicece_bwd(ctu_dtype dtype, const void* logits, int32_t ldl, const float* labels, const int32_t* idx_d,
+                   const int32_t* idx_h, const int32_t* idx_w, int32_t B, int32_t D, int32_t H, int32_t W,
+                   int32_t LD, int32_t LH, int32_t LW, int32_t n_cls, const float* acc, float smooth_nr,
+                   float smooth_dr, float weight, const float* gscale, void* dlogits, ctu_stream_t stream);
+
+/* K15 fused AdamW over one flat fp32 buffer (torch.optim.AdamW semantics, main_CTUNet.py:192-193).
+ * skip: up to 16 [begin,end) element ranges left untouched (parameters whose .grad is None this step,
+ * trainer_CTUNet.py:88-89 + torch's "skip if grad is None"). */
+int ctu_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+              float eps, float weight_decay, int32_t step, const int64_t* skip_host, int32_t n_skip,
+              ctu_stream_t stream);
+/* fp32 <-> dtype casts and fills */
+int ctu_cast(const void* src, ctu_dtype src_dtype, void* dst, ctu_dtype dst_dtype, int64_t n, ctu_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTUNET_HIP_H */
