@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training volumes/second of CTUNet (ResNet d101 + ViT, patch_frame 8) on 96^3 bf16 patches.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch per GPU (per-GPU batch 2, BASELINE.json configs[3]/[4]):
+zero grads -> forward under autocast(bf16) -> 5-head DiceCE with on-device deep-supervision targets -> backward
+(+ RCCL gradient all-reduce overlapped on a side stream when N > 1) -> fused AdamW.  Synthetic inputs (image
+U[0,1), labels randint(0,14), generator seed 1000+rank) are resident in HBM before the timed region.  W warm-up steps,
+then exactly K steps bracketed by barrier + torch.cuda.synchronize() on both sides; the time is the MAX over ranks;
+rank 0 prints ONE JSON line.
+
+Extra objects in that line (DESIGN.md section "Measurement"):
+  roofline     live HIP-event timing of the dominant kernel (the implicit-GEMM family) over instrumented steps run
+               right after the timed region: achieved = algorithmic FLOPs of its launches / their summed duration.
+  cpu_baseline the oracle (CPU restatement of the reference, kind "port") timed on this box's host cores on a bounded
+               sample: ONE 96^3 volume through forward + loss + backward + AdamW.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+FLOP_PER_VOLUME = {"ctunet": 10.26e12, "cunet": 5.278e12, "tunet": 3.496e12}  # fwd+bwd, SURVEY.md section 8d
+
+
+class KernelTimer:
+    """Collects (entry point, algorithmic FLOPs, event pair) for every implicit-GEMM launch."""
+
+    names = {"ctu_igemm_nt", "ctu_igemm_tn"}
+
+    def __init__(self):
+        self.rec = []
+
+    def add(self, name, args, e0, e1):
+        g = args[5] if name == "ctu_igemm_nt" else args[6]
+        taps = g.kd * g.kh * g.kw
+        rows_out = g.B * g.Do * g.Ho * g.Wo
+        rows_in = g.B * g.Di * g.Hi * g.Wi
+        k = g.C1 + g.C2
+        if name == "ctu_igemm_nt" and g.mode == 1:
+            # data gradient of a (possibly strided) conv: algorithmic MACs = those of the forward conv it differentiates
+            flops = 2.0 * rows_in * g.N * k * taps
+        else:
+            flops = 2.0 * rows_out * g.N * k * taps
+        self.rec.append((name, flops, e0, e1))
+
+    def summary(self):
+        out = {}
+        for name, flops, e0, e1 in self.rec:
+            ms = e0.elapsed_time(e1)
+            s = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            s["launches"] += 1
+            s["flops"] += flops
+            s["ms"] += ms
+        return out
+
+
+def cpu_baseline(model_name, threads):
+    """Oracle on the host cores: one 96^3 volume, fwd + loss + bwd + AdamW, fp32."""
+    from oracle import ctunet_oracle as O
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    m = O.build(model_name)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=1e-5)
+    x, y = O.synthetic_batch(1, seed=1000)
+    t0 = time.time()
+    opt.zero_grad(set_to_none=True)
+    loss = O.LOSSES[model_name](m(x), y)
+    loss.backward()
+    opt.step()
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "volumes/s", "cores": threads, "kind": "port",
+            "sample": f"1 volume (1x1x96x96x96), one {model_name} d101 step fwd+DiceCE+bwd+AdamW, fp32 oracle, "
+                      f"torch {torch.__version__} CPU, {dt:.1f} s, loss {loss.item():.4f}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="ctunet", choices=["ctunet", "cunet", "tunet"])
+    ap.add_argument("--batch", type=int, default=2, help="per-GPU batch (BASELINE: 2)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--bucket-mb", type=float, default=32.0)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+
+    import hybrid_ctunet_amd as H
+    from hybrid_ctunet_amd import _lib
+    from oracle.ctunet_oracle import synthetic_batch  # only the seeded input generator, not a compute path
+
+    torch.manual_seed(0)  # identical default init on every rank (and DataParallel broadcasts rank 0 anyway)
+    model = H.build_model(a.model).to(dev)
+    n_params = sum(p.numel() for p in model.parameters())
+    order = H.gradient_ready_order(model)
+    flat = H.FlatParams(order)
+    dp = H.DataParallel(model, flat=flat, bucket_mb=a.bucket_mb) if world > 1 else None
+    opt = H.FusedAdamW(None, lr=1e-4, weight_decay=1e-5, flat=flat)
+    loss_fn = H.LOSSES[a.model]
+    x, y = synthetic_batch(a.batch, seed=1000 + rank)
+    x, y = x.to(dev), y.to(dev)
+    use_bf16 = a.precision == "bf16"
+
+    def step():
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
+            out = model(x)
+            loss = loss_fn(out, y)
+        loss.backward()
+        if dp is not None:
+            dp.finish()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        loss = step()
+    if a.warmup > 0:
+        opt.freeze_skip_ranges()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = loss.item()
+
+    roofline = None
+    if not a.no_roofline and rank == 0:
+        timer = KernelTimer()
+        _lib.PROFILER = timer
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        _lib.PROFILER = None
+        s = timer.summary()
+        dom = max(s, key=lambda k: s[k]["ms"])
+        tot = {k: round(v["ms"] / 2, 3) for k, v in s.items()}
+        ach = s[dom]["flops"] / (s[dom]["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": dom,
+                    "launches_per_step": s[dom]["launches"] // 2,
+                    "avg_launch_ms": round(s[dom]["ms"] / s[dom]["launches"], 4),
+                    "igemm_ms_per_step": tot,
+                    "note": "HIP events around every implicit-GEMM launch over 2 instrumented steps after the timed region"}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        vols = a.batch * world * a.steps
+        value = vols / elapsed
+        whole_path = value * FLOP_PER_VOLUME[a.model] / world / 1e12
+        res = {
+            "metric": "train volumes/sec (96^3 patches) CTUNet d101 pf8" if a.model == "ctunet"
+                      else f"train volumes/sec (96^3 patches) {a.model}",
+            "value": round(value, 4), "unit": "volumes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if use_bf16 else "f32", "data": "synthetic",
+            "config": {"workload": f"{a.model} d101 pf8, per-GPU batch {a.batch} x 1x96x96x96, fwd + DiceCE "
+                                   f"(deep supervision, on-device targets) + bwd + fused AdamW"
+                                   + (" + RCCL bucketed grad all-reduce" if world > 1 else ""),
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "params_M": round(n_params / 1e6, 2),
+                       "final_loss": round(final_loss, 5)},
+            "whole_path_tflops_per_gpu": round(whole_path, 2),
+            "whole_path_frac_of_mfma_peak": round(whole_path / PEAK_BF16_TFLOPS, 4),
+        }
+        if roofline is not None:
+            res["roofline"] = roofline
+        if world == 1 and not a.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            res["cpu_baseline"] = cpu_baseline(a.model, threads)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,29 @@
+"""hybrid-ctunet_amd — MI355X-native (gfx950) implementation of Hybrid-CTUNet's volumetric forward/backward hot path.
+
+The directory name carries a hyphen (it mirrors the reference repository's name); import it as ``hybrid_ctunet_amd``
+through the shim module at the repository root, which registers this directory under that name.
+
+    from hybrid_ctunet_amd.networks.hybrid_CTUNet import CTUNet, CUNet, TUNet   # drop-in for the reference's import
+
+Nothing here falls back to eager PyTorch or to the CPU: the kernels live in csrc/libctunet_hip.so (built by
+``__graft_entry__.build()``), and every op raises if that library or a HIP device is missing.
+"""
+from .networks.hybrid_CTUNet import CTUNet, CUNet, TUNet  # noqa: F401
+from .train import (DataParallel, FlatParams, FusedAdamW, LOSSES, ctunet_loss, cunet_loss, dice_ce_loss,  # noqa: F401
+                    gradient_ready_order, tunet_loss)
+
+__all__ = ["CTUNet", "CUNet", "TUNet", "DataParallel", "FlatParams", "FusedAdamW", "LOSSES", "ctunet_loss",
+           "cunet_loss", "tunet_loss", "dice_ce_loss", "gradient_ready_order"]
+
+
+def build_model(name: str, model_depth: int = 101, **kw):
+    """'ctunet' | 'cunet' | 'tunet' with the BASELINE.json configuration (14 classes, 96^3 ROI, patch_frame 8)."""
+    common = dict(in_channels=1, dim_conv_stem=64, out_channels=14, img_size=(96, 96), frames=96, patch_frame=8)
+    common.update(kw)
+    if name == "ctunet":
+        return CTUNet(model_depth=model_depth, **common)
+    if name == "cunet":
+        return CUNet(out_channels=common["out_channels"], model_depth=model_depth)
+    if name == "tunet":
+        return TUNet(**common)
+    raise ValueError(name)

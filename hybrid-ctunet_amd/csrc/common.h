@@ -1,0 +1,90 @@
+// Device-side helpers shared by all kernels of libctunet_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ctunet_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+#define LRELU_SLOPE 0.01f
+#define NORM_EPS 1e-5f
+
+void ctu_set_error(const char* fmt, ...);
+int ctu_check_launch(const char* what);
+
+#define CTU_REQUIRE(cond, ...)      \
+  do {                              \
+    if (!(cond)) {                  \
+      ctu_set_error(__VA_ARGS__);   \
+      return CTU_ERR_ARG;           \
+    }                               \
+  } while (0)
+
+// dispatch a templated launcher on the activation dtype
+#define CTU_DISPATCH(dtype, CALL_F32, CALL_BF16)                    \
+  do {                                                              \
+    if ((dtype) == CTU_F32) { CALL_F32; }                           \
+    else if ((dtype) == CTU_BF16) { CALL_BF16; }                    \
+    else { ctu_set_error("bad dtype %d", (int)(dtype)); return CTU_ERR_ARG; } \
+  } while (0)
+
+// ---- 8-element vector access: 16 B for bf16, 2 x 16 B for f32 -------------------------------------------
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+__device__ __forceinline__ void load8(const bf16* p, float (&v)[8]) {
+  const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+  f32x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+  *reinterpret_cast<f32x4*>(p) = a;
+  *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+__device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
+  bf16x8 a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = (bf16)v[i];
+  *reinterpret_cast<bf16x8*>(p) = a;
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+  return x;
+}
+// reduction over aligned groups of `width` lanes (power of two <= 64)
+__device__ __forceinline__ float group_sum(float x, int width) {
+  for (int o = width >> 1; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+static inline unsigned grid_for(int64_t work_items, int block, int64_t cap = 8192) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (unsigned)g;
+}

@@ -1,0 +1,687 @@
+// Implicit-GEMM kernels on MFMA for channels-last volumes (gfx950).
+//
+//   igemm_nt : out[m][n] = sum_tap sum_c A[gather(m,tap)][c] * W[tap][n][c]      (conv fwd / dgrad, linear, convT)
+//   igemm_tn : dw[tap][n][c] += sum_m P[m][n] * Q[gather(m,tap)][c]              (weight gradients)
+//
+// Both are templated on the element type: bf16 uses v_mfma_f32_32x32x16_bf16, f32 (parity mode) uses the exact
+// v_mfma_f32_32x32x2_f32.  A lane's fragment is always "8 consecutive k of one row", so the two types share
+// the LDS image and all indexing; only Mma<T>::mma differs.
+//
+// Replaces (reference call sites): nn.Conv3d / nn.ConvTranspose3d built by get_conv_layer (networks/resnet.py:17-50)
+// and nn.Linear (networks/vit.py:36-62,117; networks/hybrid_CTUNet.py:402-679), forward and backward.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// MFMA wrappers.  Fragment = 8 consecutive-k elements of one row (lane r = row, lane half h -> k = 8h..8h+7)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T> struct Mma;
+
+template <> struct Mma<bf16> {
+  typedef bf16x8 Frag;
+  static __device__ __forceinline__ Frag load(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+  // k-strided gather (transposed operand): element j at p[j*stride]
+  static __device__ __forceinline__ Frag gather(const bf16* p, int stride) {
+    Frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = p[j * stride];
+    return f;
+  }
+  static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <> struct Mma<float> {
+  struct Frag { float v[8]; };
+  static __device__ __forceinline__ Frag load(const float* p) {
+    Frag f;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.v[j] = lo[j]; f.v[4 + j] = hi[j]; }
+    return f;
+  }
+  static __device__ __forceinline__ Frag gather(const float* p, int stride) {
+    Frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = p[j * stride];
+    return f;
+  }
+  // 32x32x2: lane (r,h) supplies A[r][k=h], B[k=h][r]; step j pairs k = j (h=0) with k = 8+j (h=1) on both operands
+  static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ bool gather_coord(int o, int t, int s, int p, int n_in, int mode, int& i) {
+  if (mode == 0) {
+    i = o * s - p + t;
+    return (unsigned)i < (unsigned)n_in;
+  }
+  const int z = o + p - t;  // stride is 1 or 2 in mode 1 (checked on the host)
+  if (z < 0) return false;
+  i = (s == 1) ? z : (z >> 1);
+  return ((s == 1) || !(z & 1)) && i < n_in;
+}
+
+// XCD-aware bijective remap of a 1-D block id: blocks dealt round-robin to 8 XCDs get contiguous tile ranges,
+// so neighbouring tiles (which share halo voxels / weight panels) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, rr = nwg & 7, x = bid & 7;
+  return (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + (bid >> 3);
+}
+
+struct NtArgs {
+  const void* a1;
+  const void* a2;
+  const void* w;
+  void* out;
+  ctu_geom g;
+  ctu_epilogue ep;
+  int M, K, taps, kchunks, tiles_n, nwg;
+};
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void igemm_nt_kernel(const NtArgs p) {
+  constexpr int BM = 128, BK = 32;
+  constexpr int EV = 16 / sizeof(T);  // elements per 16-byte vector
+  constexpr int VR = BK / EV;         // vectors per tile row
+  constexpr int LDT = BK + EV;        // padded LDS row (elements): 80 B (bf16) / 144 B (f32)
+  constexpr int RPP = 256 / VR;       // tile rows covered per pass of the 256 threads
+  constexpr int NA = BM / RPP;
+  constexpr int NB = BN / RPP;
+  constexpr int WN = BN / 2;          // wave tile: 64 rows x WN cols
+  constexpr int NJ = WN / 32;
+  constexpr int A_ELEMS = BM * LDT, B_ELEMS = BN * LDT;
+  constexpr int STAGE_LD = WN + 4;
+  constexpr size_t LDS_MAIN = 2 * (size_t)(A_ELEMS + B_ELEMS) * sizeof(T);
+  constexpr size_t LDS_EPI = 4 * 32 * (size_t)STAGE_LD * sizeof(float);
+  constexpr size_t LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  T* sA = reinterpret_cast<T*>(smem);
+  T* sB = sA + 2 * A_ELEMS;
+
+  const ctu_geom& g = p.g;
+  const int tid = threadIdx.x;
+  const int part = tid % VR, rsub = tid / VR;
+  const int tile = xcd_remap(blockIdx.x, p.nwg);
+  const int m0 = (tile / p.tiles_n) * BM;
+  const int n0 = (tile % p.tiles_n) * BN;
+  const int M = p.M, K = p.K, N = g.N, C1 = g.C1, C2 = g.C2;
+  const T* a1 = reinterpret_cast<const T*>(p.a1);
+  const T* a2 = reinterpret_cast<const T*>(p.a2);
+  const T* wp = reinterpret_cast<const T*>(p.w);
+
+  // per-thread A rows: decompose once
+  int row_b[NA], row_d[NA], row_h[NA], row_w[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int m = m0 + rsub + i * RPP;
+    if (m < M) {
+      int t = m;
+      row_w[i] = t % g.Wo; t /= g.Wo;
+      row_h[i] = t % g.Ho; t /= g.Ho;
+      row_d[i] = t % g.Do;
+      row_b[i] = t / g.Do;
+    } else {
+      row_b[i] = -1; row_d[i] = row_h[i] = row_w[i] = 0;
+    }
+  }
+
+  u32x4 ra[NA], rb[NB];
+  auto load_tiles = [&](int it) {
+    const int tap = it / p.kchunks;
+    const int c = (it - tap * p.kchunks) * BK + part * EV;
+    const int tw = tap % g.kw;
+    const int tq = tap / g.kw;
+    const int th = tq % g.kh;
+    const int td = tq / g.kh;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      int id, ih, iw;
+      bool ok = row_b[i] >= 0 && c < K;
+      ok = ok && gather_coord(row_d[i], td, g.sd, g.pd, g.Di, g.mode, id);
+      ok = ok && gather_coord(row_h[i], th, g.sh, g.ph, g.Hi, g.mode, ih);
+      ok = ok && gather_coord(row_w[i], tw, g.sw, g.pw, g.Wi, g.mode, iw);
+      if (ok) {
+        const size_t vox = (((size_t)row_b[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw;
+        const T* src = (c < C1) ? a1 + vox * C1 + c : a2 + vox * C2 + (c - C1);
+        v = *reinterpret_cast<const u32x4*>(src);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      const int n = n0 + rsub + i * RPP;
+      if (n < N && c < K) v = *reinterpret_cast<const u32x4*>(wp + ((size_t)tap * N + n) * K + c);
+      rb[i] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      *reinterpret_cast<u32x4*>(&sA[buf * A_ELEMS + (rsub + i * RPP) * LDT + part * EV]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      *reinterpret_cast<u32x4*>(&sB[buf * B_ELEMS + (rsub + i * RPP) * LDT + part * EV]) = rb[i];
+  };
+
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int n_it = p.taps * p.kchunks;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  for (int it = 0; it < n_it; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < n_it) load_tiles(it + 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      typename Mma<T>::Frag fa[2], fb[NJ];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        fa[i] = Mma<T>::load(&sA[buf * A_ELEMS + (wm * 64 + i * 32 + r) * LDT + kk * 16 + h * 8]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        fb[j] = Mma<T>::load(&sB[buf * B_ELEMS + (wn * WN + j * 32 + r) * LDT + kk * 16 + h * 8]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+    }
+    if (it + 1 < n_it) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS (fp32) -> 8-wide row vectors -> bias / GELU / residual -> global ----
+  const ctu_epilogue& ep = p.ep;
+  float* stage = reinterpret_cast<float*>(smem) + wave * 32 * STAGE_LD;
+  T* out = reinterpret_cast<T*>(p.out);
+  T* out2 = reinterpret_cast<T*>(ep.out2);
+  const T* res = reinterpret_cast<const T*>(ep.residual);
+  constexpr int VPR = WN / 8;
+  constexpr int NV = 32 * VPR / 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        stage[row * STAGE_LD + j * 32 + r] = acc[i][j][e];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int v = lane + 64 * q;
+      const int row = v / VPR, cv = v % VPR;
+      const int m = m0 + wm * 64 + i * 32 + row;
+      const int n = n0 + wn * WN + cv * 8;
+      if (m < M && n < N) {
+        float x[8];
+        load8(&stage[row * STAGE_LD + cv * 8], x);
+        if (ep.bias) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] += ep.bias[n + e];
+        }
+        if (ep.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = gelu_erf(x[e]);
+        }
+        T* dst = out;
+        size_t off;
+        if (ep.scatter) {
+          const int tap = n / ep.n_per_tap, co = n - tap * ep.n_per_tap;
+          const int tw = tap % ep.sc_kw;
+          const int tq = tap / ep.sc_kw;
+          const int th = tq % ep.sc_kh, td = tq / ep.sc_kh;
+          int t = m;
+          const int ww = t % ep.sc_W; t /= ep.sc_W;
+          const int hh = t % ep.sc_H; t /= ep.sc_H;
+          const int dd = t % ep.sc_D;
+          const int bb = t / ep.sc_D;
+          const size_t orow = (((size_t)bb * (ep.sc_D * ep.sc_kd) + dd * ep.sc_kd + td) * (ep.sc_H * ep.sc_kh) +
+                               hh * ep.sc_kh + th) * (size_t)(ep.sc_W * ep.sc_kw) + ww * ep.sc_kw + tw;
+          off = orow * ep.ldc + co;
+        } else if (ep.n_split > 0 && n >= ep.n_split) {
+          dst = out2;
+          off = (size_t)m * ep.ldc2 + (n - ep.n_split);
+        } else {
+          off = (size_t)m * ep.ldc + n;
+        }
+        if (res) {
+          float rr[8];
+          load8(res + off, rr);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] += rr[e];
+        }
+        store8(dst + off, x);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+static int launch_nt(const void* a1, const void* a2, const void* w, void* out, const ctu_geom* g,
+                     const ctu_epilogue* ep, hipStream_t stream) {
+  NtArgs p;
+  p.a1 = a1; p.a2 = a2; p.w = w; p.out = out; p.g = *g; p.ep = *ep;
+  const int64_t M64 = (int64_t)g->B * g->Do * g->Ho * g->Wo;
+  p.M = (int)M64;
+  p.K = g->C1 + g->C2;
+  p.taps = g->kd * g->kh * g->kw;
+  p.kchunks = (p.K + 31) / 32;
+  const int tiles_m = (p.M + 127) / 128;
+  if (g->N <= 64) {
+    p.tiles_n = (g->N + 63) / 64;
+    p.nwg = tiles_m * p.tiles_n;
+    hipLaunchKernelGGL((igemm_nt_kernel<T, 64>), dim3(p.nwg), dim3(256), 0, stream, p);
+  } else {
+    p.tiles_n = (g->N + 127) / 128;
+    p.nwg = tiles_m * p.tiles_n;
+    hipLaunchKernelGGL((igemm_nt_kernel<T, 128>), dim3(p.nwg), dim3(256), 0, stream, p);
+  }
+  return ctu_check_launch("igemm_nt");
+}
+
+static int check_geom(const ctu_geom* g) {
+  CTU_REQUIRE(g != nullptr, "geom is null");
+  CTU_REQUIRE(g->B > 0 && g->Di > 0 && g->Hi > 0 && g->Wi > 0 && g->Do > 0 && g->Ho > 0 && g->Wo > 0, "bad dims");
+  CTU_REQUIRE(g->C1 > 0 && g->C1 % 8 == 0 && g->C2 >= 0 && g->C2 % 8 == 0, "C1/C2 must be multiples of 8 (%d,%d)",
+              g->C1, g->C2);
+  CTU_REQUIRE(g->C2 == 0 || g->C1 % 32 == 0, "concatenated source needs C1 %% 32 == 0 (C1=%d)", g->C1);
+  CTU_REQUIRE(g->N > 0 && g->N % 8 == 0, "N must be a multiple of 8 (%d)", g->N);
+  CTU_REQUIRE(g->kd > 0 && g->kh > 0 && g->kw > 0 && g->sd > 0 && g->sh > 0 && g->sw > 0, "bad kernel/stride");
+  CTU_REQUIRE(g->mode == 0 || g->mode == 1, "bad mode %d", g->mode);
+  if (g->mode == 1)
+    CTU_REQUIRE(g->sd <= 2 && g->sh <= 2 && g->sw <= 2, "mode 1 supports stride 1 or 2 only");
+  const int64_t M = (int64_t)g->B * g->Do * g->Ho * g->Wo;
+  const int64_t Vin = (int64_t)g->B * g->Di * g->Hi * g->Wi;
+  CTU_REQUIRE(M < (1ll << 31) - 256 && Vin < (1ll << 31), "volume too large for 32-bit row indices");
+  return CTU_OK;
+}
+
+extern "C" int ctu_igemm_nt(ctu_dtype dtype, const void* a1, const void* a2, const void* w, void* out,
+                            const ctu_geom* g, const ctu_epilogue* ep, ctu_stream_t stream) {
+  if (int rc = check_geom(g)) return rc;
+  CTU_REQUIRE(a1 && w && out && ep, "null pointer");
+  CTU_REQUIRE(g->C2 == 0 || a2, "C2 > 0 needs a2");
+  CTU_REQUIRE(ep->ldc > 0 && ep->ldc % 8 == 0, "ldc must be a positive multiple of 8");
+  CTU_REQUIRE(ep->n_split % 8 == 0 && (ep->n_split == 0 || (ep->out2 && ep->ldc2 % 8 == 0)), "bad split epilogue");
+  if (ep->scatter) {
+    CTU_REQUIRE(ep->n_per_tap > 0 && ep->n_per_tap % 8 == 0 && g->N % ep->n_per_tap == 0, "bad scatter n_per_tap");
+    CTU_REQUIRE(g->N / ep->n_per_tap == ep->sc_kd * ep->sc_kh * ep->sc_kw, "scatter taps mismatch");
+    CTU_REQUIRE((int64_t)g->B * ep->sc_D * ep->sc_H * ep->sc_W == (int64_t)g->B * g->Do * g->Ho * g->Wo,
+                "scatter grid mismatch");
+    CTU_REQUIRE(ep->n_split == 0, "scatter and split are exclusive");
+  }
+  CTU_DISPATCH(dtype, return launch_nt<float>(a1, a2, w, out, g, ep, (hipStream_t)stream),
+               return launch_nt<bf16>(a1, a2, w, out, g, ep, (hipStream_t)stream));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------------------
+struct TnArgs {
+  const void* p;
+  const void* q1;
+  const void* q2;
+  float* dw;
+  ctu_geom g;
+  int ldp, M, C, taps, rows_per_split, tiles_c;
+  unsigned long long magic_w, magic_h, magic_d;  // ceil(2^32 / d)
+};
+
+// floor(x / d) for 0 <= x < 2^31: the rounded-up reciprocal over-estimates by at most 1, fixed by one compare
+__device__ __forceinline__ int fast_div(int x, unsigned long long magic, int d) {
+  int q = (int)(((unsigned long long)(unsigned)x * magic) >> 32);
+  if (q * d > x) --q;
+  return q;
+}
+
+template <typename T, int TN, int TC>
+__global__ __launch_bounds__(256) void igemm_tn_kernel(const TnArgs a) {
+  constexpr int BKM = 64;  // rows (voxels) per iteration; wave w reduces rows [16w, 16w+16)
+  constexpr int EV = 16 / sizeof(T);
+  constexpr int LDP = TN + EV, LDQ = TC + EV;
+  constexpr int VP = TN / EV, VQ = TC / EV;  // vectors per row
+  constexpr int NP = (BKM * VP + 255) / 256, NQ = (BKM * VQ + 255) / 256;
+  constexpr int RP = 256 / VP, RQ = 256 / VQ;  // rows per pass
+  constexpr int TI = TN / 32, TJ = TC / 32;
+  __shared__ __attribute__((aligned(16))) T sP[2][BKM * LDP];
+  __shared__ __attribute__((aligned(16))) T sQ[2][BKM * LDQ];
+
+  const ctu_geom& g = a.g;
+  const int tid = threadIdx.x;
+  const int n0 = (blockIdx.x / a.tiles_c) * TN;
+  const int c0 = (blockIdx.x % a.tiles_c) * TC;
+  const int tap = blockIdx.y;
+  const int tw = tap % g.kw;
+  const int tq = tap / g.kw;
+  const int th = tq % g.kh, td = tq / g.kh;
+  const int m_begin = blockIdx.z * a.rows_per_split;
+  const int m_end = min(a.M, m_begin + a.rows_per_split);
+  const int N = g.N, C = a.C, C1 = g.C1, C2 = g.C2;
+  const T* P = reinterpret_cast<const T*>(a.p);
+  const T* Q1 = reinterpret_cast<const T*>(a.q1);
+  const T* Q2 = reinterpret_cast<const T*>(a.q2);
+
+  const int p_part = tid % VP, p_row = tid / VP;
+  const int q_part = tid % VQ, q_row = tid / VQ;
+  u32x4 rp[NP], rq[NQ];
+
+  auto load_tiles = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      const int row = p_row + i * RP;
+      const int m = mb + row;
+      const int n = n0 + p_part * EV;
+      if (row < BKM && m < m_end && n < N) v = *reinterpret_cast<const u32x4*>(P + (size_t)m * a.ldp + n);
+      rp[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      const int row = q_row + i * RQ;
+      const int m = mb + row;
+      const int c = c0 + q_part * EV;
+      if (row < BKM && m < m_end && c < C) {
+        int t = m;
+        int q = fast_div(t, a.magic_w, g.Wo);
+        const int ow = t - q * g.Wo; t = q;
+        q = fast_div(t, a.magic_h, g.Ho);
+        const int oh = t - q * g.Ho; t = q;
+        q = fast_div(t, a.magic_d, g.Do);
+        const int od = t - q * g.Do;
+        const int b = q;
+        int id, ih, iw;
+        bool ok = gather_coord(od, td, g.sd, g.pd, g.Di, g.mode, id);
+        ok = ok && gather_coord(oh, th, g.sh, g.ph, g.Hi, g.mode, ih);
+        ok = ok && gather_coord(ow, tw, g.sw, g.pw, g.Wi, g.mode, iw);
+        if (ok) {
+          const size_t vox = (((size_t)b * g.Di + id) * g.Hi + ih) * g.Wi + iw;
+          const T* src = (c < C1) ? Q1 + vox * C1 + c : Q2 + vox * C2 + (c - C1);
+          v = *reinterpret_cast<const u32x4*>(src);
+        }
+      }
+      rq[i] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int row = p_row + i * RP;
+      if (row < BKM) *reinterpret_cast<u32x4*>(&sP[buf][row * LDP + p_part * EV]) = rp[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int row = q_row + i * RQ;
+      if (row < BKM) *reinterpret_cast<u32x4*>(&sQ[buf][row * LDQ + q_part * EV]) = rq[i];
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (m_begin < m_end) {
+    load_tiles(m_begin);
+    store_tiles(0);
+    __syncthreads();
+    int buf = 0;
+    for (int mb = m_begin; mb < m_end; mb += BKM) {
+      const bool more = mb + BKM < m_end;
+      if (more) load_tiles(mb + BKM);
+      const int krow = wave * 16 + h * 8;
+      typename Mma<T>::Frag fa[TI], fb[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) fa[i] = Mma<T>::gather(&sP[buf][krow * LDP + i * 32 + r], LDP);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) fb[j] = Mma<T>::gather(&sQ[buf][krow * LDQ + j * 32 + r], LDQ);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+      if (more) store_tiles(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  // every wave adds its partial tile (its 16-row slices) into the fp32 panel
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int c = c0 + j * 32 + r;
+        if (n < N && c < C) atomicAdd(&a.dw[((size_t)tap * N + n) * C + c], acc[i][j][e]);
+      }
+}
+
+static unsigned long long magic32(int d) { return ((1ull << 32) + (unsigned long long)d - 1) / (unsigned long long)d; }
+
+template <typename T>
+static int launch_tn(const void* p, int ldp, const void* q1, const void* q2, float* dw, const ctu_geom* g,
+                     hipStream_t stream) {
+  TnArgs a;
+  a.p = p; a.q1 = q1; a.q2 = q2; a.dw = dw; a.g = *g; a.ldp = ldp;
+  a.M = (int)((int64_t)g->B * g->Do * g->Ho * g->Wo);
+  a.C = g->C1 + g->C2;
+  a.taps = g->kd * g->kh * g->kw;
+  a.magic_w = magic32(g->Wo); a.magic_h = magic32(g->Ho); a.magic_d = magic32(g->Do);
+  const bool small_n = g->N <= 32, small_c = a.C <= 32;
+  const int TN = small_n ? 32 : 64, TC = small_c ? 32 : 64;
+  const int tiles_n = (g->N + TN - 1) / TN;
+  a.tiles_c = (a.C + TC - 1) / TC;
+  const int tiles = tiles_n * a.tiles_c * a.taps;
+  int splits = (2048 + tiles - 1) / tiles;
+  const int max_splits = (a.M + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  if (splits > 65535) splits = 65535;
+  int rps = (a.M + splits - 1) / splits;
+  rps = ((rps + 63) / 64) * 64;
+  splits = (a.M + rps - 1) / rps;
+  a.rows_per_split = rps;
+  dim3 grid(tiles_n * a.tiles_c, a.taps, splits);
+  if (small_n && small_c) hipLaunchKernelGGL((igemm_tn_kernel<T, 32, 32>), grid, dim3(256), 0, stream, a);
+  else if (small_n) hipLaunchKernelGGL((igemm_tn_kernel<T, 32, 64>), grid, dim3(256), 0, stream, a);
+  else if (small_c) hipLaunchKernelGGL((igemm_tn_kernel<T, 64, 32>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((igemm_tn_kernel<T, 64, 64>), grid, dim3(256), 0, stream, a);
+  return ctu_check_launch("igemm_tn");
+}
+
+extern "C" int ctu_igemm_tn(ctu_dtype dtype, const void* p, int32_t ldp, const void* q1, const void* q2, float* dw,
+                            const ctu_geom* g, ctu_stream_t stream) {
+  if (int rc = check_geom(g)) return rc;
+  CTU_REQUIRE(p && q1 && dw, "null pointer");
+  CTU_REQUIRE(g->C2 == 0 || q2, "C2 > 0 needs q2");
+  CTU_REQUIRE(ldp >= g->N && ldp % 8 == 0, "ldp must be >= N and a multiple of 8");
+  CTU_REQUIRE(g->kd * g->kh * g->kw <= 65535, "too many taps");
+  CTU_DISPATCH(dtype, return launch_tn<float>(p, ldp, q1, q2, dw, g, (hipStream_t)stream),
+               return launch_tn<bf16>(p, ldp, q1, q2, dw, g, (hipStream_t)stream));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Cin == 1 convolutions (direct, VALU): 3x3x3 s1 first conv and the 7x7x7 s(2,2,1) ResNet stem
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv_cin1_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                            T* __restrict__ out, const ctu_geom g, const int M) {
+  // block: 256 threads = 32 voxels x 8 channel-groups of 8; loops over 64-channel slabs of N
+  extern __shared__ float sw[];  // [kh*kw][64] weights of the current kd plane / n-slab
+  const int tid = threadIdx.x;
+  const int cg = tid & 7, vloc = tid >> 3;
+  const int m = blockIdx.x * 32 + vloc;
+  const int plane = g.kh * g.kw;
+  int b = 0, od = 0, oh = 0, ow = 0;
+  const bool valid = m < M;
+  if (valid) {
+    int t = m;
+    ow = t % g.Wo; t /= g.Wo;
+    oh = t % g.Ho; t /= g.Ho;
+    od = t % g.Do;
+    b = t / g.Do;
+  }
+  for (int nb = 0; nb < g.N; nb += 64) {
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int td = 0; td < g.kd; ++td) {
+      __syncthreads();
+      for (int i = tid; i < plane * 64; i += 256) {
+        const int t = i >> 6, n = i & 63;
+        sw[i] = w[(size_t)(td * plane + t) * g.N + nb + n];
+      }
+      __syncthreads();
+      const int id = od * g.sd - g.pd + td;
+      if (valid && (unsigned)id < (unsigned)g.Di) {
+        for (int th = 0; th < g.kh; ++th) {
+          const int ih = oh * g.sh - g.ph + th;
+          if ((unsigned)ih >= (unsigned)g.Hi) continue;
+          const T* xrow = x + (((size_t)b * g.Di + id) * g.Hi + ih) * g.Wi;
+          for (int tw = 0; tw < g.kw; ++tw) {
+            const int iw = ow * g.sw - g.pw + tw;
+            if ((unsigned)iw >= (unsigned)g.Wi) continue;
+            const float xv = (float)xrow[iw];
+            float wv[8];
+            load8(&sw[(th * g.kw + tw) * 64 + cg * 8], wv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(xv, wv[e], acc[e]);
+          }
+        }
+      }
+    }
+    if (valid) store8(out + (size_t)m * g.N + nb + cg * 8, acc);
+  }
+}
+
+// dw[tap][n] += sum_m dy[m][n] * x[gather(m,tap)].  block = KD waves; wave kd holds the kh*kw taps of plane kd for
+// 64 channels (lane = channel): KH*KW accumulators per lane, statically indexed.
+template <typename T, int KD, int KH, int KW>
+__global__ __launch_bounds__(64 * KD) void conv_cin1_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                  float* __restrict__ dw, const ctu_geom g, const int M,
+                                                                  const int rows_per_block) {
+  const int lane = threadIdx.x & 63;
+  const int td = threadIdx.x >> 6;
+  const int nb = blockIdx.y * 64;
+  float acc[KH][KW];
+#pragma unroll
+  for (int i = 0; i < KH; ++i)
+#pragma unroll
+    for (int j = 0; j < KW; ++j) acc[i][j] = 0.f;
+  const int m_begin = blockIdx.x * rows_per_block;
+  const int m_end = min(M, m_begin + rows_per_block);
+  int t = m_begin;
+  int ow = t % g.Wo; t /= g.Wo;
+  int oh = t % g.Ho; t /= g.Ho;
+  int od = t % g.Do;
+  int b = t / g.Do;
+  for (int m = m_begin; m < m_end; ++m) {
+    const float d = (float)dy[(size_t)m * g.N + nb + lane];
+    const int id = od * g.sd - g.pd + td;
+    if ((unsigned)id < (unsigned)g.Di) {
+#pragma unroll
+      for (int th = 0; th < KH; ++th) {
+        const int ih = oh * g.sh - g.ph + th;
+        if ((unsigned)ih < (unsigned)g.Hi) {
+          const T* xrow = x + (((size_t)b * g.Di + id) * g.Hi + ih) * g.Wi;
+#pragma unroll
+          for (int tw = 0; tw < KW; ++tw) {
+            const int iw = ow * g.sw - g.pw + tw;
+            const float xv = ((unsigned)iw < (unsigned)g.Wi) ? (float)xrow[iw] : 0.f;
+            acc[th][tw] = fmaf(d, xv, acc[th][tw]);
+          }
+        }
+      }
+    }
+    if (++ow == g.Wo) {
+      ow = 0;
+      if (++oh == g.Ho) {
+        oh = 0;
+        if (++od == g.Do) { od = 0; ++b; }
+      }
+    }
+  }
+#pragma unroll
+  for (int th = 0; th < KH; ++th)
+#pragma unroll
+    for (int tw = 0; tw < KW; ++tw)
+      atomicAdd(&dw[(size_t)((td * KH + th) * KW + tw) * g.N + nb + lane], acc[th][tw]);
+}
+
+static int check_cin1(const ctu_geom* g) {
+  if (int rc = check_geom(g)) return rc;
+  CTU_REQUIRE(g->mode == 0, "cin1 conv: mode must be 0");
+  CTU_REQUIRE(g->N % 64 == 0, "cin1 conv: N must be a multiple of 64 (%d)", g->N);
+  CTU_REQUIRE((g->kd == 3 && g->kh == 3 && g->kw == 3) || (g->kd == 7 && g->kh == 7 && g->kw == 7) ||
+                  (g->kd == 1 && g->kh == 1 && g->kw == 1),
+              "cin1 conv: kernel must be 1x1x1, 3x3x3 or 7x7x7");
+  return CTU_OK;
+}
+
+extern "C" int ctu_conv_cin1_fwd(ctu_dtype dtype, const void* x, const float* w, void* out, const ctu_geom* gin,
+                                 ctu_stream_t stream) {
+  CTU_REQUIRE(gin, "geom is null");
+  ctu_geom g = *gin;
+  g.C1 = 8; g.C2 = 0;  // channel fields unused here (Cin == 1); keep check_geom happy
+  if (int rc = check_cin1(&g)) return rc;
+  CTU_REQUIRE(x && w && out, "null pointer");
+  const int M = (int)((int64_t)g.B * g.Do * g.Ho * g.Wo);
+  const size_t lds = (size_t)g.kh * g.kw * 64 * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  CTU_DISPATCH(dtype,
+               hipLaunchKernelGGL(conv_cin1_fwd_kernel<float>, dim3((M + 31) / 32), dim3(256), lds, s, (const float*)x,
+                                  w, (float*)out, g, M),
+               hipLaunchKernelGGL(conv_cin1_fwd_kernel<bf16>, dim3((M + 31) / 32), dim3(256), lds, s, (const bf16*)x, w,
+                                  (bf16*)out, g, M));
+  return ctu_check_launch("conv_cin1_fwd");
+}
+
+template <typename T>
+static int launch_cin1_wgrad(const void* x, const void* dy, float* dw, const ctu_geom& g, hipStream_t s) {
+  const int M = (int)((int64_t)g.B * g.Do * g.Ho * g.Wo);
+  const int rows = 512;
+  dim3 grid((M + rows - 1) / rows, g.N / 64);
+  if (g.kd == 1)
+    hipLaunchKernelGGL((conv_cin1_wgrad_kernel<T, 1, 1, 1>), grid, dim3(64), 0, s, (const T*)x, (const T*)dy, dw, g, M,
+                       rows);
+  else if (g.kd == 3)
+    hipLaunchKernelGGL((conv_cin1_wgrad_kernel<T, 3, 3, 3>), grid, dim3(64 * 3), 0, s, (const T*)x, (const T*)dy, dw, g,
+                       M, rows);
+  else
+    hipLaunchKernelGGL((conv_cin1_wgrad_kernel<T, 7, 7, 7>), grid, dim3(64 * 7), 0, s, (const T*)x, (const T*)dy, dw, g,
+                       M, rows);
+  return ctu_check_launch("conv_cin1_wgrad");
+}
+
+extern "C" int ctu_conv_cin1_wgrad(ctu_dtype dtype, const void* x, const void* dy, float* dw, const ctu_geom* gin,
+                                   ctu_stream_t stream) {
+  CTU_REQUIRE(gin, "geom is null");
+  ctu_geom g = *gin;
+  g.C1 = 8; g.C2 = 0;
+  if (int rc = check_cin1(&g)) return rc;
+  CTU_REQUIRE(x && dy && dw, "null pointer");
+  CTU_DISPATCH(dtype, return launch_cin1_wgrad<float>(x, dy, dw, g, (hipStream_t)stream),
+               return launch_cin1_wgrad<bf16>(x, dy, dw, g, (hipStream_t)stream));
+}

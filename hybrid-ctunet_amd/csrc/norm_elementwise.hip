@@ -1,0 +1,775 @@
+// HBM-bound kernels: InstanceNorm3d(+residual)(+LeakyReLU), LayerNorm, GELU, adds, layout permutes, casts,
+// and the binary cross-weight fusion core.  All access is 8 elements per lane (16 B bf16 / 2x16 B f32),
+// channels-last, coalesced along C.  Reductions: wavefront shuffles -> LDS -> one fp32 atomic per block.
+#include "common.h"
+
+// =========================================================================================================
+// InstanceNorm3d  (resnet.py:97-124,156-157,198; hybrid_CTUNet.py:84-104): x [B][S][C]
+// =========================================================================================================
+// stats[b][c] = (sum, sumsq).  grid (chunks, B); block 256 = (C/8 column groups) x (256/(C/8) row lanes)
+template <typename T>
+__global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ x, float* __restrict__ stats,
+                                                       const int64_t S, const int C, const int64_t rows_per_block) {
+  __shared__ float red[256 * 16];
+  const int ncg = C >> 3;                 // column groups (<= 256, checked on host)
+  const int tid = threadIdx.x;
+  const int cg = tid % ncg, rl = tid / ncg;
+  const int rlanes = 256 / ncg;
+  const int b = blockIdx.y;
+  const int64_t s_begin = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t s_end = min(S, s_begin + rows_per_block);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  if (rl < rlanes) {
+    const T* base = x + ((size_t)b * S) * C + cg * 8;
+    for (int64_t s = s_begin + rl; s < s_end; s += rlanes) {
+      float v[8];
+      load8(base + (size_t)s * C, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s1[e]; red[tid * 16 + 8 + e] = s2[e]; }
+  __syncthreads();
+  // thread t < C*2 reduces one (channel, which) over the row lanes
+  for (int o = tid; o < C * 2; o += 256) {
+    const int c = o >> 1, which = o & 1;
+    const int g = c >> 3, e = c & 7;
+    float acc = 0.f;
+    for (int r = 0; r < rlanes; ++r) acc += red[(r * ncg + g) * 16 + which * 8 + e];
+    atomicAdd(&stats[((size_t)b * C + c) * 2 + which], acc);
+  }
+}
+
+__device__ __forceinline__ void in_mean_rstd(const float* stats, int b, int C, int c0, float inv_s, float (&mean)[8],
+                                             float (&rstd)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float s1 = stats[((size_t)b * C + c0 + e) * 2], s2 = stats[((size_t)b * C + c0 + e) * 2 + 1];
+    const float mu = s1 * inv_s;
+    const float var = fmaxf(s2 * inv_s - mu * mu, 0.f);
+    mean[e] = mu;
+    rstd[e] = rsqrtf(var + NORM_EPS);
+  }
+}
+
+// y = act((x - mean) * rstd + residual); one thread per 8-channel vector, grid-stride over B*S*C/8 vectors
+template <typename T>
+__global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                       const T* __restrict__ res, T* __restrict__ y, const int B,
+                                                       const int64_t S, const int C, const int act) {
+  const int ncg = C >> 3;
+  const int64_t nvec = (int64_t)B * S * ncg;
+  const float inv_s = 1.0f / (float)S;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(i % ncg);
+    const int b = (int)(i / ((int64_t)S * ncg));
+    float mean[8], rstd[8], v[8];
+    in_mean_rstd(stats, b, C, cg * 8, inv_s, mean, rstd);
+    load8(x + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean[e]) * rstd[e];
+    if (res) {
+      float r[8];
+      load8(res + i * 8, r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
+    if (act) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * LRELU_SLOPE;
+    }
+    store8(y + i * 8, v);
+  }
+}
+
+// sums[b][c] = (sum g, sum g*xhat), g = dy * act'(y)
+template <typename T>
+__global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const T* __restrict__ y, const float* __restrict__ stats,
+                                                            float* __restrict__ sums, const int64_t S, const int C,
+                                                            const int act, const int64_t rows_per_block) {
+  __shared__ float red[256 * 16];
+  const int ncg = C >> 3;
+  const int tid = threadIdx.x;
+  const int cg = tid % ncg, rl = tid / ncg;
+  const int rlanes = 256 / ncg;
+  const int b = blockIdx.y;
+  const int64_t s_begin = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t s_end = min(S, s_begin + rows_per_block);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  if (rl < rlanes) {
+    float mean[8], rstd[8];
+    in_mean_rstd(stats, b, C, cg * 8, 1.0f / (float)S, mean, rstd);
+    const size_t base = ((size_t)b * S) * C + cg * 8;
+    for (int64_t s = s_begin + rl; s < s_end; s += rlanes) {
+      float g[8], xv[8];
+      const size_t off = base + (size_t)s * C;
+      load8(dy + off, g);
+      load8(x + off, xv);
+      if (act) {
+        float yv[8];
+        load8(y + off, yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = yv[e] > 0.f ? g[e] : g[e] * LRELU_SLOPE;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s1[e] += g[e];
+        s2[e] = fmaf(g[e], (xv[e] - mean[e]) * rstd[e], s2[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s1[e]; red[tid * 16 + 8 + e] = s2[e]; }
+  __syncthreads();
+  for (int o = tid; o < C * 2; o += 256) {
+    const int c = o >> 1, which = o & 1;
+    const int g = c >> 3, e = c & 7;
+    float acc = 0.f;
+    for (int r = 0; r < rlanes; ++r) acc += red[(r * ncg + g) * 16 + which * 8 + e];
+    atomicAdd(&sums[((size_t)b * C + c) * 2 + which], acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const T* __restrict__ y, const float* __restrict__ stats,
+                                                           const float* __restrict__ sums, T* __restrict__ dx,
+                                                           T* __restrict__ dres, const int B, const int64_t S,
+                                                           const int C, const int act) {
+  const int ncg = C >> 3;
+  const int64_t nvec = (int64_t)B * S * ncg;
+  const float inv_s = 1.0f / (float)S;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(i % ncg);
+    const int b = (int)(i / ((int64_t)S * ncg));
+    float mean[8], rstd[8], g[8], xv[8];
+    in_mean_rstd(stats, b, C, cg * 8, inv_s, mean, rstd);
+    load8(dy + i * 8, g);
+    load8(x + i * 8, xv);
+    if (act) {
+      float yv[8];
+      load8(y + i * 8, yv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = yv[e] > 0.f ? g[e] : g[e] * LRELU_SLOPE;
+    }
+    if (dres) store8(dres + i * 8, g);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float m1 = sums[((size_t)b * C + cg * 8 + e) * 2] * inv_s;
+      const float m2 = sums[((size_t)b * C + cg * 8 + e) * 2 + 1] * inv_s;
+      const float xh = (xv[e] - mean[e]) * rstd[e];
+      o[e] = rstd[e] * (g[e] - m1 - xh * m2);
+    }
+    store8(dx + i * 8, o);
+  }
+}
+
+static int check_in(const void* x, int B, int64_t S, int C) {
+  CTU_REQUIRE(x, "null pointer");
+  CTU_REQUIRE(B > 0 && S > 0, "bad B/S");
+  CTU_REQUIRE(C >= 8 && C % 8 == 0 && C <= 2048, "InstanceNorm needs C %% 8 == 0 and C <= 2048 (C=%d)", C);
+  return CTU_OK;
+}
+static int64_t in_rows_per_block(int64_t S, int B) {
+  // aim for ~2048 blocks in total, at least 64 rows each
+  int64_t chunks = 2048 / (B > 0 ? B : 1);
+  if (chunks < 1) chunks = 1;
+  int64_t rows = (S + chunks - 1) / chunks;
+  if (rows < 64) rows = 64;
+  return rows;
+}
+
+extern "C" int ctu_in_stats(ctu_dtype dtype, const void* x, int32_t B, int64_t S, int32_t C, float* stats,
+                            ctu_stream_t stream) {
+  if (int rc = check_in(x, B, S, C)) return rc;
+  CTU_REQUIRE(stats, "null stats");
+  const int64_t rows = in_rows_per_block(S, B);
+  dim3 grid((unsigned)((S + rows - 1) / rows), B);
+  hipStream_t s = (hipStream_t)stream;
+  CTU_DISPATCH(dtype, hipLaunchKernelGGL(in_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)x, stats, S, C, rows),
+               hipLaunchKernelGGL(in_stats_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, stats, S, C, rows));
+  return ctu_check_launch("in_stats");
+}
+
+extern "C" int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, const void* residual, void* y,
+                            int32_t B, int64_t S, int32_t C, int32_t act, ctu_stream_t stream) {
+  if (int rc = check_in(x, B, S, C)) return rc;
+  CTU_REQUIRE(stats && y, "null pointer");
+  const unsigned grid = grid_for((int64_t)B * S * (C / 8), 256);
+  hipStream_t s = (hipStream_t)stream;
+  CTU_DISPATCH(dtype,
+               hipLaunchKernelGGL(in_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, stats,
+                                  (const float*)residual, (float*)y, B, S, C, act),
+               hipLaunchKernelGGL(in_apply_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, stats,
+                                  (const bf16*)residual, (bf16*)y, B, S, C, act));
+  return ctu_check_launch("in_apply");
+}
+
+extern "C" int ctu_in_bwd_reduce(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
+                                 float* sums, int32_t B, int64_t S, int32_t C, int32_t act, ctu_stream_t stream) {
+  if (int rc = check_in(x, B, S, C)) return rc;
+  CTU_REQUIRE(dy && stats && sums && (y || !act), "null pointer");
+  const int64_t rows = in_rows_per_block(S, B);
+  dim3 grid((unsigned)((S + rows - 1) / rows), B);
+  hipStream_t s = (hipStream_t)stream;
+  CTU_DISPATCH(dtype,
+               hipLaunchKernelGGL(in_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x,
+                                  (const float*)y, stats, sums, S, C, act, rows),
+               hipLaunchKernelGGL(in_bwd_reduce_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, (const bf16*)x,
+                                  (const bf16*)y, stats, sums, S, C, act, rows));
+  return ctu_check_launch("in_bwd_reduce");
+}
+
+extern "C" int ctu_in_bwd_apply(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
+                                const float* sums, void* dx, void* dres, int32_t B, int64_t S, int32_t C, int32_t act,
+                                ctu_stream_t stream) {
+  if (int rc = check_in(x, B, S, C)) return rc;
+  CTU_REQUIRE(dy && stats && sums && dx && (y || !act), "null pointer");
+  const unsigned grid = grid_for((int64_t)B * S * (C / 8), 256);
+  hipStream_t s = (hipStream_t)stream;
+  CTU_DISPATCH(dtype,
+               hipLaunchKernelGGL(in_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy,
+                                  (const float*)x, (const float*)y, stats, sums, (float*)dx, (float*)dres, B, S, C, act),
+               hipLaunchKernelGGL(in_bwd_apply_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)dy,
+                                  (const bf16*)x, (const bf16*)y, stats, sums, (bf16*)dx, (bf16*)dres, B, S, C, act));
+  return ctu_check_launch("in_bwd_apply");
+}
+
+// =========================================================================================================
+// LayerNorm (vit.py:35,55,116,118; hybrid_CTUNet.py:456,518,630-631): a row is held by LPR lanes, up to 4 vectors
+// of 8 per lane (dim <= LPR*32).  dim = LPR * VPL * 8.
+// =========================================================================================================
+#define LN_MAXV 4
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            float* __restrict__ mean_rstd, const int64_t rows,
+                                                            const int dim, const int lpr, const int vpl) {
+  const int tid = threadIdx.x;
+  const int rows_per_block = 256 / lpr;
+  const int sub = tid % lpr, rloc = tid / lpr;
+  const float inv_d = 1.0f / (float)dim;
+  for (int64_t row = (int64_t)blockIdx.x * rows_per_block + rloc; row < rows; row += (int64_t)gridDim.x * rows_per_block) {
+    float v[LN_MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k)
+      if (k < vpl) {
+        load8(x + (size_t)row * dim + (size_t)(sub + k * lpr) * 8, v[k]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[k][e];
+      }
+    const float mu = group_sum(s, lpr) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k)
+      if (k < vpl) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mu; q = fmaf(d, d, q); }
+      }
+    const float rstd = rsqrtf(group_sum(q, lpr) * inv_d + NORM_EPS);
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k)
+      if (k < vpl) {
+        const int c0 = (sub + k * lpr) * 8;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mu) * rstd * gamma[c0 + e] + beta[c0 + e];
+        store8(y + (size_t)row * dim + c0, o);
+      }
+    if (sub == 0) { mean_rstd[row * 2] = mu; mean_rstd[row * 2 + 1] = rstd; }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean_rstd, T* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            const int64_t rows, const int dim, const int lpr,
+                                                            const int vpl) {
+  const int tid = threadIdx.x;
+  const int rows_per_block = 256 / lpr;
+  const int sub = tid % lpr, rloc = tid / lpr;
+  const float inv_d = 1.0f / (float)dim;
+  float ag[LN_MAXV][8], ab[LN_MAXV][8];
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; }
+  for (int64_t row = (int64_t)blockIdx.x * rows_per_block + rloc; row < rows; row += (int64_t)gridDim.x * rows_per_block) {
+    const float mu = mean_rstd[row * 2], rstd = mean_rstd[row * 2 + 1];
+    float g[LN_MAXV][8], xh[LN_MAXV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k)
+      if (k < vpl) {
+        const int c0 = (sub + k * lpr) * 8;
+        float d[8], xv[8];
+        load8(dy + (size_t)row * dim + c0, d);
+        load8(x + (size_t)row * dim + c0, xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[k][e] = (xv[e] - mu) * rstd;
+          g[k][e] = d[e] * gamma[c0 + e];
+          s1 += g[k][e];
+          s2 = fmaf(g[k][e], xh[k][e], s2);
+          ag[k][e] = fmaf(d[e], xh[k][e], ag[k][e]);
+          ab[k][e] += d[e];
+        }
+      }
+    const float m1 = group_sum(s1, lpr) * inv_d, m2 = group_sum(s2, lpr) * inv_d;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k)
+      if (k < vpl) {
+        const int c0 = (sub + k * lpr) * 8;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rstd * (g[k][e] - m1 - xh[k][e] * m2);
+        store8(dx + (size_t)row * dim + c0, o);
+      }
+  }
+  // column sums: reduce the block's row lanes through LDS, then one atomic per column per block
+  __shared__ float red[256 * 8];
+  for (int k = 0; k < LN_MAXV; ++k) {
+    if (k >= vpl) break;
+    for (int which = 0; which < 2; ++which) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[tid * 8 + e] = which ? ab[k][e] : ag[k][e];
+      __syncthreads();
+      if (rloc == 0) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int r = 0; r < rows_per_block; ++r)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += red[(r * lpr + sub) * 8 + e];
+        float* dst = (which ? dbeta : dgamma) + (sub + k * lpr) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(dst + e, acc[e]);
+      }
+    }
+  }
+}
+
+static int ln_config(int dim, int* lpr, int* vpl) {
+  CTU_REQUIRE(dim >= 8 && dim % 8 == 0, "LayerNorm dim must be a multiple of 8 (%d)", dim);
+  const int nvec = dim / 8;
+  int l = 64;
+  while (l > 1 && (nvec % l != 0)) l >>= 1;
+  CTU_REQUIRE(nvec / l <= LN_MAXV, "LayerNorm dim %d unsupported (needs <= %d vectors per lane)", dim, LN_MAXV);
+  *lpr = l;
+  *vpl = nvec / l;
+  return CTU_OK;
+}
+
+extern "C" int ctu_layernorm_fwd(ctu_dtype dtype, const void* x, const float* gamma, const float* beta, void* y,
+                                 float* mean_rstd, int64_t rows, int32_t dim, ctu_stream_t stream) {
+  int lpr, vpl;
+  if (int rc = ln_config(dim, &lpr, &vpl)) return rc;
+  CTU_REQUIRE(x && gamma && beta && y && mean_rstd && rows > 0, "null pointer / bad rows");
+  const unsigned grid = grid_for(rows, 256 / lpr, 4096);
+  hipStream_t s = (hipStream_t)stream;
+  CTU_DISPATCH(dtype,
+               hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, gamma, beta,
+                                  (float*)y, mean_rstd, rows, dim, lpr, vpl),
+               hipLaunchKernelGGL(layernorm_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, gamma, beta,
+                                  (bf16*)y, mean_rstd, rows, dim, lpr, vpl));
+  return ctu_check_launch("layernorm_fwd");
+}
+
+extern "C" int ctu_layernorm_bwd(ctu_dtype dtype, const void* dy, const void* x, const float* gamma,
+                                 const float* mean_rstd, void* dx, float* dgamma, float* dbeta, int64_t rows,
+                                 int32_t dim, ctu_stream_t stream) {
+  int lpr, vpl;
+  if (int rc = ln_config(dim, &lpr, &vpl)) return rc;
+  CTU_REQUIRE(dy && x && gamma && mean_rstd && dx && dgamma && dbeta && rows > 0, "null pointer / bad rows");
+  const unsigned grid = grid_for(rows, 256 / lpr, 1024);
+  hipStream_t s = (hipStream_t)stream;
+  CTU_DISPATCH(dtype,
+               hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy,
+                                  (const float*)x, gamma, mean_rstd, (float*)dx, dgamma, dbeta, rows, dim, lpr, vpl),
+               hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)dy,
+                                  (const bf16*)x, gamma, mean_rstd, (bf16*)dx, dgamma, dbeta, rows, dim, lpr, vpl));
+  return ctu_check_launch("layernorm_bwd");
+}
+
+// =========================================================================================================
+// elementwise: GELU, add, broadcast add, cast, column sums, permutes
+// =========================================================================================================
+template <typename T, int OP>  // 0 gelu fwd (a=x), 1 gelu bwd (a=dy, b=x), 2 add
+__global__ __launch_bounds__(256) void ew_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y,
+                                                 const int64_t nvec) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    float va[8], vb[8], o[8];
+    load8(a + i * 8, va);
+    if (OP != 0) load8(b + i * 8, vb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (OP == 0) o[e] = gelu_erf(va[e]);
+      else if (OP == 1) o[e] = va[e] * gelu_erf_grad(vb[e]);
+      else o[e] = va[e] + vb[e];
+    }
+    store8(y + i * 8, o);
+  }
+}
+
+template <typename T, int OP>
+static int launch_ew(const void* a, const void* b, void* y, int64_t n, hipStream_t s, const char* name) {
+  CTU_REQUIRE(a && y && (b || OP == 0) && n > 0 && n % 8 == 0, "%s: null pointer or n %% 8 != 0", name);
+  hipLaunchKernelGGL((ew_kernel<T, OP>), dim3(grid_for(n / 8, 256)), dim3(256), 0, s, (const T*)a, (const T*)b, (T*)y,
+                     n / 8);
+  return ctu_check_launch(name);
+}
+extern "C" int ctu_gelu_fwd(ctu_dtype dtype, const void* x, void* y, int64_t n, ctu_stream_t stream) {
+  CTU_DISPATCH(dtype, return (launch_ew<float, 0>(x, nullptr, y, n, (hipStream_t)stream, "gelu_fwd")),
+               return (launch_ew<bf16, 0>(x, nullptr, y, n, (hipStream_t)stream, "gelu_fwd")));
+}
+extern "C" int ctu_gelu_bwd(ctu_dtype dtype, const void* dy, const void* x, void* dx, int64_t n, ctu_stream_t stream) {
+  CTU_DISPATCH(dtype, return (launch_ew<float, 1>(dy, x, dx, n, (hipStream_t)stream, "gelu_bwd")),
+               return (launch_ew<bf16, 1>(dy, x, dx, n, (hipStream_t)stream, "gelu_bwd")));
+}
+extern "C" int ctu_add(ctu_dtype dtype, const void* a, const void* b, void* y, int64_t n, ctu_stream_t stream) {
+  CTU_DISPATCH(dtype, return (launch_ew<float, 2>(a, b, y, n, (hipStream_t)stream, "add")),
+               return (launch_ew<bf16, 2>(a, b, y, n, (hipStream_t)stream, "add")));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_bcast_kernel(const T* __restrict__ a, const float* __restrict__ bc,
+                                                        T* __restrict__ y, const int64_t rows, const int cols,
+                                                        const int64_t period) {
+  const int ncg = cols >> 3;
+  const int64_t nvec = rows * ncg;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / ncg;
+    const int cg = (int)(i - row * ncg);
+    float v[8], w[8];
+    load8(a + i * 8, v);
+    load8(bc + (row % period) * cols + cg * 8, w);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += w[e];
+    store8(y + i * 8, v);
+  }
+}
+extern "C" int ctu_add_bcast(ctu_dtype dtype, const void* a, const float* bcast, void* y, int64_t rows, int32_t cols,
+                             int64_t period, ctu_stream_t stream) {
+  CTU_REQUIRE(a && bcast && y && rows > 0 && cols > 0 && cols % 8 == 0 && period > 0, "add_bcast: bad args");
+  const unsigned grid = grid_for(rows * (cols / 8), 256);
+  hipStream_t s = (hipStream_t)stream;
+  CTU_DISPATCH(dtype,
+               hipLaunchKernelGGL(add_bcast_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)a, bcast, (float*)y,
+                                  rows, cols, period),
+               hipLaunchKernelGGL(add_bcast_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)a, bcast, (bf16*)y,
+                                  rows, cols, period));
+  return ctu_check_launch("add_bcast");
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, const int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    dst[i] = (TD)(float)src[i];
+}
+extern "C" int ctu_cast(const void* src, ctu_dtype sd, void* dst, ctu_dtype dd, int64_t n, ctu_stream_t stream) {
+  CTU_REQUIRE(src && dst && n > 0, "cast: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = grid_for(n, 256);
+  if (sd == CTU_F32 && dd == CTU_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16>), dim3(grid), dim3(256), 0, s, (const float*)src, (bf16*)dst, n);
+  else if (sd == CTU_BF16 && dd == CTU_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(grid), dim3(256), 0, s, (const bf16*)src, (float*)dst, n);
+  else if (sd == CTU_F32 && dd == CTU_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, n);
+  else if (sd == CTU_BF16 && dd == CTU_BF16)
+    hipLaunchKernelGGL((cast_kernel<bf16, bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)src, (bf16*)dst, n);
+  else { ctu_set_error("cast: bad dtypes"); return CTU_ERR_ARG; }
+  return ctu_check_launch("cast");
+}
+
+// dst[i0*d0+i1*d1+i2*d2] (=|+=) src[i0*s0+i1*s1+i2*s2]; thread index runs over (i0,i1,i2) with i2 fastest
+template <typename TD, bool ACC>
+__global__ __launch_bounds__(256) void permute3_kernel(const float* __restrict__ src, TD* __restrict__ dst,
+                                                       const int64_t n0, const int64_t n1, const int64_t n2,
+                                                       const int64_t s0, const int64_t s1, const int64_t s2,
+                                                       const int64_t d0, const int64_t d1, const int64_t d2) {
+  const int64_t total = n0 * n1 * n2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t i2 = i % n2;
+    const int64_t t = i / n2;
+    const int64_t i1 = t % n1, i0 = t / n1;
+    const float v = src[i0 * s0 + i1 * s1 + i2 * s2];
+    TD* p = dst + i0 * d0 + i1 * d1 + i2 * d2;
+    if (ACC) *p = (TD)((float)*p + v);
+    else *p = (TD)v;
+  }
+}
+extern "C" int ctu_permute3(const float* src, void* dst, ctu_dtype dd, int64_t n0, int64_t n1, int64_t n2, int64_t s0,
+                            int64_t s1, int64_t s2, int64_t d0, int64_t d1, int64_t d2, int32_t accumulate,
+                            ctu_stream_t stream) {
+  CTU_REQUIRE(src && dst && n0 > 0 && n1 > 0 && n2 > 0, "permute3: bad args");
+  CTU_REQUIRE(!accumulate || dd == CTU_F32, "permute3: accumulate needs an fp32 destination");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = grid_for(n0 * n1 * n2, 256);
+  if (dd == CTU_F32 && accumulate)
+    hipLaunchKernelGGL((permute3_kernel<float, true>), dim3(grid), dim3(256), 0, s, src, (float*)dst, n0, n1, n2, s0, s1,
+                       s2, d0, d1, d2);
+  else if (dd == CTU_F32)
+    hipLaunchKernelGGL((permute3_kernel<float, false>), dim3(grid), dim3(256), 0, s, src, (float*)dst, n0, n1, n2, s0, s1,
+                       s2, d0, d1, d2);
+  else if (dd == CTU_BF16)
+    hipLaunchKernelGGL((permute3_kernel<bf16, false>), dim3(grid), dim3(256), 0, s, src, (bf16*)dst, n0, n1, n2, s0, s1,
+                       s2, d0, d1, d2);
+  else { ctu_set_error("permute3: bad dtype"); return CTU_ERR_ARG; }
+  return ctu_check_launch("permute3");
+}
+
+// out[n] += sum_m x[m][n]; block: 256 threads = (N/8 col groups, capped) x row lanes
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, const int64_t M, const int N, const int ld,
+                                                     float* __restrict__ out, const int64_t rows_per_block) {
+  __shared__ float red[256 * 8];
+  const int ncg = N >> 3;
+  const int tid = threadIdx.x;
+  const int gpb = ncg < 256 ? ncg : 256;  // column groups handled per block pass
+  const int rlanes = 256 / gpb;
+  const int cgl = tid % gpb, rl = tid / gpb;
+  const int64_t m_begin = (int64_t)blockIdx.x * rows_per_block, m_end = min(M, m_begin + rows_per_block);
+  for (int cg0 = 0; cg0 < ncg; cg0 += gpb) {
+    const int cg = cg0 + cgl;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (rl < rlanes && cg < ncg)
+      for (int64_t m = m_begin + rl; m < m_end; m += rlanes) {
+        float v[8];
+        load8(x + (size_t)m * ld + cg * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[tid * 8 + e] = acc[e];
+    __syncthreads();
+    if (rl == 0 && cg < ncg) {
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = 0.f;
+      for (int r = 0; r < rlanes; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] += red[(r * gpb + cgl) * 8 + e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(&out[cg * 8 + e], t[e]);
+    }
+  }
+}
+extern "C" int ctu_colsum(ctu_dtype dtype, const void* x, int64_t M, int32_t N, int32_t ld, float* out,
+                          ctu_stream_t stream) {
+  CTU_REQUIRE(x && out && M > 0 && N > 0 && N % 8 == 0 && ld >= N && ld % 8 == 0, "colsum: bad args");
+  int64_t rows = (M + 1023) / 1024;
+  if (rows < 64) rows = 64;
+  const unsigned grid = (unsigned)((M + rows - 1) / rows);
+  hipStream_t s = (hipStream_t)stream;
+  CTU_DISPATCH(dtype,
+               hipLaunchKernelGGL(colsum_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, M, N, ld, out, rows),
+               hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, M, N, ld, out, rows));
+  return ctu_check_launch("colsum");
+}
+
+// patchify: x [B][H][W][F] (c = 1) -> tokens [B][(h w f)][(p1 p2 pf)]   (vit.py:115)
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ x, T* __restrict__ tok, const int B,
+                                                       const int H, const int W, const int F, const int p1, const int p2,
+                                                       const int p3) {
+  const int nh = H / p1, nw = W / p2, nf = F / p3;
+  const int64_t total = (int64_t)B * H * W * F;
+  const int pd = p1 * p2 * p3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // i indexes the OUTPUT: (((b*nh + h)*nw + w)*nf + f)*pd + ((i1*p2 + i2)*p3 + i3)
+    const int e = (int)(i % pd);
+    int64_t t = i / pd;
+    const int f = (int)(t % nf); t /= nf;
+    const int w = (int)(t % nw); t /= nw;
+    const int h = (int)(t % nh);
+    const int b = (int)(t / nh);
+    const int i3 = e % p3, i2 = (e / p3) % p2, i1 = e / (p3 * p2);
+    tok[i] = x[(((size_t)b * H + h * p1 + i1) * W + w * p2 + i2) * F + f * p3 + i3];
+  }
+}
+extern "C" int ctu_patchify(ctu_dtype dtype, const void* x, void* tokens, int32_t B, int32_t H, int32_t W, int32_t F,
+                            int32_t p1, int32_t p2, int32_t p3, ctu_stream_t stream) {
+  CTU_REQUIRE(x && tokens && B > 0 && H % p1 == 0 && W % p2 == 0 && F % p3 == 0, "patchify: bad args");
+  const unsigned grid = grid_for((int64_t)B * H * W * F, 256);
+  hipStream_t s = (hipStream_t)stream;
+  CTU_DISPATCH(dtype,
+               hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)tokens, B,
+                                  H, W, F, p1, p2, p3),
+               hipLaunchKernelGGL(patchify_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)tokens, B, H,
+                                  W, F, p1, p2, p3));
+  return ctu_check_launch("patchify");
+}
+
+// pixel shuffle (hybrid_CTUNet.py:420-428): y[b][d*p1+i1][h*p2+i2][w*p3+i3][cc] = x[b][d][h][w][((cc*p1+i1)*p2+i2)*p3+i3]
+// thread per output element group of 8 consecutive cc (requires c % 8 == 0): source elements are strided by p1*p2*p3.
+template <typename T, bool INV>
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const T* __restrict__ x, T* __restrict__ y, const int B,
+                                                            const int D, const int H, const int W, const int c,
+                                                            const int p1, const int p2, const int p3) {
+  const int P = p1 * p2 * p3;
+  const int ncg = c >> 3;
+  const int64_t total = (int64_t)B * D * p1 * H * p2 * W * p3 * ncg;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(i % ncg);
+    int64_t t = i / ncg;
+    const int ow = (int)(t % (W * p3)); t /= (W * p3);
+    const int oh = (int)(t % (H * p2)); t /= (H * p2);
+    const int od = (int)(t % (D * p1));
+    const int b = (int)(t / (D * p1));
+    const int w = ow / p3, i3 = ow % p3, h = oh / p2, i2 = oh % p2, d = od / p1, i1 = od % p1;
+    const size_t big = ((((size_t)b * D + d) * H + h) * W + w) * (size_t)(c * P) + (size_t)(cg * 8) * P +
+                       (size_t)((i1 * p2 + i2) * p3 + i3);
+    const size_t small = (size_t)i * 8;
+    if (!INV) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (float)x[big + (size_t)e * P];
+      store8(y + small, v);
+    } else {  // x is the shuffled-layout tensor (gradient), y the original layout
+      float v[8];
+      load8(x + small, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[big + (size_t)e * P] = (T)v[e];
+    }
+  }
+}
+extern "C" int ctu_pixel_shuffle(ctu_dtype dtype, const void* x, void* y, int32_t B, int32_t D, int32_t H, int32_t W,
+                                 int32_t c, int32_t p1, int32_t p2, int32_t p3, int32_t inverse, ctu_stream_t stream) {
+  CTU_REQUIRE(x && y && B > 0 && D > 0 && H > 0 && W > 0 && c > 0 && c % 8 == 0 && p1 > 0 && p2 > 0 && p3 > 0,
+              "pixel_shuffle: bad args (c must be a multiple of 8)");
+  const unsigned grid = grid_for((int64_t)B * D * H * W * p1 * p2 * p3 * (c / 8), 256);
+  hipStream_t s = (hipStream_t)stream;
+#define PS_LAUNCH(T, INV) \
+  hipLaunchKernelGGL((pixel_shuffle_kernel<T, INV>), dim3(grid), dim3(256), 0, s, (const T*)x, (T*)y, B, D, H, W, c, p1, p2, p3)
+  if (inverse) { CTU_DISPATCH(dtype, PS_LAUNCH(float, true), PS_LAUNCH(bf16, true)); }
+  else { CTU_DISPATCH(dtype, PS_LAUNCH(float, false), PS_LAUNCH(bf16, false)); }
+#undef PS_LAUNCH
+  return ctu_check_launch("pixel_shuffle");
+}
+
+// =========================================================================================================
+// binary cross-weight fusion core (hybrid_CTUNet.py:651-665).  4 lanes per (token, head of 32 channels).
+// =========================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void pwa_fwd_kernel(const T* __restrict__ qkv1, const T* __restrict__ qkv2,
+                                                      T* __restrict__ out, const int64_t rows, const int C,
+                                                      const float scale) {
+  const int ncg = C >> 3;
+  const int64_t nvec = rows * ncg;  // multiple of 4 (C % 32 == 0)
+  const int64_t nvec_pad = (nvec + 255) / 256 * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec_pad; i += (int64_t)gridDim.x * 256) {
+    const bool ok = i < nvec;
+    const int64_t row = ok ? i / ncg : 0;
+    const int c0 = ok ? (int)(i - row * ncg) * 8 : 0;
+    const T* r1 = qkv1 + (size_t)row * 3 * C;
+    const T* r2 = qkv2 + (size_t)row * 3 * C;
+    float q1[8], k1[8], v1[8], q2[8], k2[8], v2[8];
+    load8(r1 + c0, q1); load8(r1 + C + c0, k1); load8(r1 + 2 * C + c0, v1);
+    load8(r2 + c0, q2); load8(r2 + C + c0, k2); load8(r2 + 2 * C + c0, v2);
+    float z = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z += q2[e] * k1[e] - q1[e] * k2[e];
+    z = group_sum(z, 4) * scale;          // d1 - d2 over the head's 32 channels
+    const float a1 = 1.0f / (1.0f + __expf(-z));
+    if (ok) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = a1 * v1[e] + (1.0f - a1) * v2[e];
+      store8(out + (size_t)row * C + c0, o);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pwa_bwd_kernel(const T* __restrict__ qkv1, const T* __restrict__ qkv2,
+                                                      const T* __restrict__ dout, T* __restrict__ dqkv1,
+                                                      T* __restrict__ dqkv2, const int64_t rows, const int C,
+                                                      const float scale) {
+  const int ncg = C >> 3;
+  const int64_t nvec = rows * ncg;
+  const int64_t nvec_pad = (nvec + 255) / 256 * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec_pad; i += (int64_t)gridDim.x * 256) {
+    const bool ok = i < nvec;
+    const int64_t row = ok ? i / ncg : 0;
+    const int c0 = ok ? (int)(i - row * ncg) * 8 : 0;
+    const T* r1 = qkv1 + (size_t)row * 3 * C;
+    const T* r2 = qkv2 + (size_t)row * 3 * C;
+    float q1[8], k1[8], v1[8], q2[8], k2[8], v2[8], go[8];
+    load8(r1 + c0, q1); load8(r1 + C + c0, k1); load8(r1 + 2 * C + c0, v1);
+    load8(r2 + c0, q2); load8(r2 + C + c0, k2); load8(r2 + 2 * C + c0, v2);
+    load8(dout + (size_t)row * C + c0, go);
+    float z = 0.f, da = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      z += q2[e] * k1[e] - q1[e] * k2[e];
+      da += go[e] * (v1[e] - v2[e]);
+    }
+    z = group_sum(z, 4) * scale;
+    da = group_sum(da, 4);
+    const float a1 = 1.0f / (1.0f + __expf(-z));
+    const float dz = da * a1 * (1.0f - a1) * scale;
+    if (ok) {
+      float o[8];
+      T* g1 = dqkv1 + (size_t)row * 3 * C;
+      T* g2 = dqkv2 + (size_t)row * 3 * C;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = -dz * k2[e];
+      store8(g1 + c0, o);               // dq1
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = dz * q2[e];
+      store8(g1 + C + c0, o);           // dk1
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = a1 * go[e];
+      store8(g1 + 2 * C + c0, o);       // dv1
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = dz * k1[e];
+      store8(g2 + c0, o);               // dq2
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = -dz * q1[e];
+      store8(g2 + C + c0, o);           // dk2
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (1.0f - a1) * go[e];
+      store8(g2 + 2 * C + c0, o);       // dv2
+    }
+  }
+}
+
+extern "C" int ctu_pwa_fwd(ctu_dtype dtype, const void* qkv1, const void* qkv2, void* out, int64_t rows, int32_t C,
+                           float scale, ctu_stream_t stream) {
+  CTU_REQUIRE(qkv1 && qkv2 && out && rows > 0 && C > 0 && C % 32 == 0, "pwa_fwd: bad args (C %% 32)");
+  const unsigned grid = grid_for(rows * (C / 8), 256);
+  hipStream_t s = (hipStream_t)stream;
+  CTU_DISPATCH(dtype,
+               hipLaunchKernelGGL(pwa_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)qkv1,
+                                  (const float*)qkv2, (float*)out, rows, C, scale),
+               hipLaunchKernelGGL(pwa_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)qkv1, (const bf16*)qkv2,
+                                  (bf16*)out, rows, C, scale));
+  return ctu_check_launch("pwa_fwd");
+}
+extern "C" int ctu_pwa_bwd(ctu_dtype dtype, const void* qkv1, const void* qkv2, const void* dout, void* dqkv1,
+                           void* dqkv2, int64_t rows, int32_t C, float scale, ctu_stream_t stream) {
+  CTU_REQUIRE(qkv1 && qkv2 && dout && dqkv1 && dqkv2 && rows > 0 && C > 0 && C % 32 == 0, "pwa_bwd: bad args");
+  const unsigned grid = grid_for(rows * (C / 8), 256);
+  hipStream_t s = (hipStream_t)stream;
+  CTU_DISPATCH(dtype,
+               hipLaunchKernelGGL(pwa_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)qkv1,
+                                  (const float*)qkv2, (const float*)dout, (float*)dqkv1, (float*)dqkv2, rows, C, scale),
+               hipLaunchKernelGGL(pwa_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)qkv1, (const bf16*)qkv2,
+                                  (const bf16*)dout, (bf16*)dqkv1, (bf16*)dqkv2, rows, C, scale));
+  return ctu_check_launch("pwa_bwd");
+}

@@ -1,0 +1,544 @@
+"""Autograd glue between torch tensors and the libctunet_hip.so kernels.
+
+Every op is a torch.autograd.Function whose forward/backward launch hand-written HIP kernels through the C ABI on
+torch's current HIP stream.  Activations are channels-last: a volume is a contiguous [B, D, H, W, C] tensor
+(== row-major [rows, C] matrix), dtype float32 (parity mode) or bfloat16.  Parameters stay fp32 in the layout of
+the reference's state_dict; packed panels for the MFMA kernels are cached per (parameter version, weights epoch).
+"""
+from __future__ import annotations
+
+import math
+import weakref
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import AttnGeom, Epilogue, Geom, call, dcode, ptr, stream
+
+LRELU_SLOPE = 0.01
+
+# ---------------------------------------------------------------------------------------------------------------
+# packed-weight cache
+# ---------------------------------------------------------------------------------------------------------------
+_weights_epoch = 0
+_pack_cache = weakref.WeakKeyDictionary()  # nn.Parameter -> {(kind, dtype): (version key, packed tensor)}
+
+
+def bump_weights_epoch():
+    """Call after parameters were modified by something torch's version counter cannot see (the fused AdamW)."""
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def _packed(param: torch.Tensor, kind: str, dtype: torch.dtype, builder):
+    """Packed panel of a parameter, rebuilt when the parameter changes.  Only nn.Parameter objects are cached (keyed
+    by object identity, weakly): temporaries could alias a freed tensor's address."""
+    if not isinstance(param, torch.nn.Parameter):
+        with torch.no_grad():
+            return builder()
+    ver = (param._version, _weights_epoch, param.data_ptr(), tuple(param.shape))
+    slot = _pack_cache.get(param)
+    if slot is None:
+        slot = {}
+        _pack_cache[param] = slot
+    hit = slot.get((kind, dtype))
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    with torch.no_grad():
+        t = builder()
+    slot[(kind, dtype)] = (ver, t)
+    return t
+
+
+def permute3(src: torch.Tensor, dst: torch.Tensor, n, s, d, accumulate=False):
+    """dst[i0*d0+i1*d1+i2*d2] (+)= src[i0*s0+i1*s1+i2*s2]; src fp32."""
+    assert src.dtype == torch.float32
+    call("ctu_permute3", ptr(src), ptr(dst), dcode(dst.dtype), n[0], n[1], n[2], s[0], s[1], s[2], d[0], d[1], d[2],
+         1 if accumulate else 0, stream())
+
+
+def _t3(v) -> Tuple[int, int, int]:
+    return tuple(int(x) for x in v) if isinstance(v, (tuple, list)) else (int(v),) * 3
+
+
+def _geom(B, din, dout, C1, C2, N, k=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), mode=0) -> Geom:
+    return Geom(B, din[0], din[1], din[2], dout[0], dout[1], dout[2], C1, C2, N, k[0], k[1], k[2], s[0], s[1], s[2],
+                p[0], p[1], p[2], mode)
+
+
+def _plain_geom(M, K, N) -> Geom:
+    return _geom(1, (M, 1, 1), (M, 1, 1), K, 0, N)
+
+
+def _epi(ldc, bias=None, residual=None, act=0, out2=None, n_split=0, ldc2=0, scatter=None) -> Epilogue:
+    e = Epilogue()
+    e.bias = ptr(bias)
+    e.residual = ptr(residual)
+    e.act = act
+    e.ldc = ldc
+    e.out2 = ptr(out2)
+    e.n_split = n_split
+    e.ldc2 = ldc2
+    if scatter is not None:
+        e.scatter = 1
+        (e.n_per_tap, e.sc_D, e.sc_H, e.sc_W, e.sc_kd, e.sc_kh, e.sc_kw) = scatter
+    else:
+        e.scatter = 0
+    return e
+
+
+def _check_act(x: torch.Tensor):
+    L.require_device(x)
+    if not x.is_contiguous():
+        raise RuntimeError("hybrid-ctunet_amd ops expect contiguous channels-last activations")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GEMM-shaped ops
+# ---------------------------------------------------------------------------------------------------------------
+def _igemm_nt(x1, x2, w, out, g: Geom, e: Epilogue):
+    call("ctu_igemm_nt", dcode(x1.dtype), ptr(x1), ptr(x2), ptr(w), ptr(out), g, e, stream())
+
+
+def _igemm_tn(p, ldp, q1, q2, dw, g: Geom):
+    call("ctu_igemm_tn", dcode(p.dtype), ptr(p), ldp, ptr(q1), ptr(q2), ptr(dw), g, stream())
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x @ W^T + b) (+ residual).  x: [..., K]; W: [N, K] fp32 (nn.Linear / 1x1x1 conv layout).
+    Reference: nn.Linear at vit.py:36,39,59,62,117 and hybrid_CTUNet.py:402,457,465,519,522,632-633,641,679;
+    1x1x1 nn.Conv3d at resnet.py:96,100 and hybrid_CTUNet.py:75-83."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, act: int):
+        _check_act(x)
+        N, K = weight.shape[0], weight[0].numel()
+        M = x.numel() // K
+        w2 = weight.reshape(N, K)
+        wf = w2 if x.dtype == torch.float32 and w2.is_contiguous() else _packed(
+            weight, "lin_f", x.dtype, lambda: w2.detach().to(x.dtype).contiguous())
+        pre = None
+        out = torch.empty((*x.shape[:-1], N), dtype=x.dtype, device=x.device)
+        if act == 1 and any(ctx.needs_input_grad[:3]):
+            # keep the pre-activation for GELU'
+            pre = torch.empty_like(out)
+            _igemm_nt(x, None, wf, pre, _plain_geom(M, K, N), _epi(N, bias=bias))
+            call("ctu_gelu_fwd", dcode(x.dtype), ptr(pre), ptr(out), out.numel(), stream())
+            if residual is not None:
+                call("ctu_add", dcode(x.dtype), ptr(out), ptr(residual), ptr(out), out.numel(), stream())
+        else:
+            _igemm_nt(x, None, wf, out, _plain_geom(M, K, N), _epi(N, bias=bias, residual=residual, act=act))
+        ctx.save_for_backward(x, weight, pre)
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.act = act
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, pre = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, K = weight.shape[0], weight[0].numel()
+        M = x.numel() // K
+        gres = gy if ctx.has_res else None
+        g = gy
+        if ctx.act == 1:
+            g = torch.empty_like(gy)
+            call("ctu_gelu_bwd", dcode(gy.dtype), ptr(gy), ptr(pre), ptr(g), gy.numel(), stream())
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wd = _packed(weight, "lin_d", x.dtype, lambda: weight.detach().reshape(N, K).t().to(x.dtype).contiguous())
+            gx = torch.empty_like(x)
+            _igemm_nt(g, None, wd, gx, _plain_geom(M, N, K), _epi(K))
+        if ctx.needs_input_grad[1]:
+            gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+            _igemm_tn(g, N, x, None, gw, _plain_geom(M, K, N))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = torch.zeros(N, dtype=torch.float32, device=x.device)
+            call("ctu_colsum", dcode(g.dtype), ptr(g), M, N, N, ptr(gb), stream())
+        return gx, gw, gb, gres, None
+
+
+def linear(x, weight, bias=None, residual=None, act: int = 0):
+    return LinearFn.apply(x, weight, bias, residual, act)
+
+
+class ConvFn(torch.autograd.Function):
+    """nn.Conv3d(bias=False) on channels-last volumes, input optionally the channel-concat of two tensors
+    (torch.cat at hybrid_CTUNet.py:199,618 folded into the K loop).  x: [B,D,H,W,C]; weight: [N, C1+C2, kd,kh,kw].
+    Reference: get_conv_layer, networks/resnet.py:17-50 (3x3x3 s1/s2, 1x1x1 s2)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, stride, padding):
+        _check_act(x1)
+        B, D, H, W, C1 = x1.shape
+        C2 = 0 if x2 is None else x2.shape[-1]
+        N = weight.shape[0]
+        k = tuple(weight.shape[2:])
+        taps = k[0] * k[1] * k[2]
+        K = C1 + C2
+        assert weight.shape[1] == K
+        dout = tuple((n + 2 * p - kk) // s + 1 for n, p, kk, s in zip((D, H, W), padding, k, stride))
+        wf = _packed(weight, "conv_f", x1.dtype,
+                     lambda: _pack(weight, (taps, N, K), (1, K * taps, taps), x1.dtype))
+        out = torch.empty((B, *dout, N), dtype=x1.dtype, device=x1.device)
+        g = _geom(B, (D, H, W), dout, C1, C2, N, k, stride, padding, 0)
+        _igemm_nt(x1, x2, wf, out, g, _epi(N))
+        ctx.save_for_backward(x1, x2, weight)
+        ctx.cfg = (stride, padding, k, dout)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x1, x2, weight = ctx.saved_tensors
+        stride, padding, k, dout = ctx.cfg
+        gy = gy.contiguous()
+        B, D, H, W, C1 = x1.shape
+        C2 = 0 if x2 is None else x2.shape[-1]
+        N, K = weight.shape[0], C1 + C2
+        taps = k[0] * k[1] * k[2]
+        g1 = g2 = gw = None
+        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
+            # dX[v][c] = sum_t sum_n dY[(v + p - t)/s][n] W[n][c][t]  ->  panel [t][c][n]
+            wd = _packed(weight, "conv_d", x1.dtype,
+                         lambda: _pack(weight, (taps, K, N), (1, taps, K * taps), x1.dtype))
+            g1 = torch.empty_like(x1)
+            g2 = torch.empty_like(x2) if x2 is not None else None
+            gd = _geom(B, dout, (D, H, W), N, 0, K, k, stride, padding, 1)
+            _igemm_nt(gy, None, wd, g1, gd, _epi(C1, out2=g2, n_split=C1 if x2 is not None else 0, ldc2=C2))
+        if ctx.needs_input_grad[2]:
+            panel = torch.zeros((taps, N, K), dtype=torch.float32, device=x1.device)
+            gq = _geom(B, (D, H, W), dout, C1, C2, N, k, stride, padding, 0)
+            _igemm_tn(gy, N, x1, x2, panel, gq)
+            if taps == 1:
+                gw = panel.view(weight.shape)
+            else:
+                gw = torch.empty(weight.shape, dtype=torch.float32, device=x1.device)
+                permute3(panel, gw, (N, K, taps), (K, 1, N * K), (K * taps, taps, 1))
+        return g1, g2, gw, None, None
+
+
+def _pack(weight, n, src_strides, dtype):
+    """out[i0][i1][i2] = weight.flat[i0*s0 + i1*s1 + i2*s2] cast to dtype (weight fp32, contiguous)."""
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    out = torch.empty(n, dtype=dtype, device=w.device)
+    permute3(w, out, n, src_strides, (n[1] * n[2], n[2], 1))
+    return out
+
+
+def conv3d(x1, weight, stride=1, padding=0, x2=None):
+    return ConvFn.apply(x1, x2, weight, _t3(stride), _t3(padding))
+
+
+class ConvTransposeFn(torch.autograd.Function):
+    """nn.ConvTranspose3d with kernel == stride, padding 0, bias=False (hybrid_CTUNet.py:177-185,232-240,286-294):
+    a GEMM [M, Cin] x [Cin, taps*Cout] whose epilogue scatters each tap to its output voxel.
+    weight: [Cin, Cout, kd, kh, kw]."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        _check_act(x)
+        B, D, H, W, Cin = x.shape
+        Cout = weight.shape[1]
+        k = tuple(weight.shape[2:])
+        taps = k[0] * k[1] * k[2]
+        M = B * D * H * W
+        wf = _packed(weight, "convt_f", x.dtype,
+                     lambda: _pack(weight, (taps, Cout, Cin), (1, taps, Cout * taps), x.dtype))
+        out = torch.empty((B, D * k[0], H * k[1], W * k[2], Cout), dtype=x.dtype, device=x.device)
+        g = _geom(B, (D, H, W), (D, H, W), Cin, 0, taps * Cout)
+        _igemm_nt(x, None, wf, out, g, _epi(Cout, scatter=(Cout, D, H, W, k[0], k[1], k[2])))
+        ctx.save_for_backward(x, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, D, H, W, Cin = x.shape
+        Cout = weight.shape[1]
+        k = tuple(weight.shape[2:])
+        taps = k[0] * k[1] * k[2]
+        dbig = (D * k[0], H * k[1], W * k[2])
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            # dX[v][ci] = sum_t sum_co dY[v*k + t][co] W[ci][co][t]: a stride-k conv over dY; panel [t][ci][co]
+            wd = _packed(weight, "convt_d", x.dtype,
+                         lambda: _pack(weight, (taps, Cin, Cout), (1, Cout * taps, taps), x.dtype))
+            gx = torch.empty_like(x)
+            _igemm_nt(gy, None, wd, gx, _geom(B, dbig, (D, H, W), Cout, 0, Cin, k, k, (0, 0, 0), 0), _epi(Cin))
+        if ctx.needs_input_grad[1]:
+            # dW[ci][co][t] = sum_v x[v][ci] dY[v*k + t][co]: P = x (N := Cin), Q = dY gathered (C := Cout)
+            panel = torch.zeros((taps, Cin, Cout), dtype=torch.float32, device=x.device)
+            _igemm_tn(x, Cin, gy, None, panel, _geom(B, dbig, (D, H, W), Cout, 0, Cin, k, k, (0, 0, 0), 0))
+            gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            permute3(panel, gw, (Cin, Cout, taps), (Cout, 1, Cin * Cout), (Cout * taps, taps, 1))
+        return gx, gw
+
+
+def conv_transpose3d(x, weight):
+    return ConvTransposeFn.apply(x, weight)
+
+
+class ConvCin1Fn(torch.autograd.Function):
+    """nn.Conv3d with one input channel (vit_encoder0.conv1, hybrid_CTUNet.py:57-65; stem, resnet.py:150-155).
+    x: [B, D, H, W, 1]; weight [N, 1, kd, kh, kw]; direct VALU kernels; no input gradient (x is the image)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding):
+        _check_act(x)
+        B, D, H, W, _ = x.shape
+        N = weight.shape[0]
+        k = tuple(weight.shape[2:])
+        taps = k[0] * k[1] * k[2]
+        dout = tuple((n + 2 * p - kk) // s + 1 for n, p, kk, s in zip((D, H, W), padding, k, stride))
+        wf = _packed(weight, "cin1_f", torch.float32, lambda: _pack(weight, (1, taps, N), (0, 1, taps), torch.float32))
+        out = torch.empty((B, *dout, N), dtype=x.dtype, device=x.device)
+        g = _geom(B, (D, H, W), dout, 8, 0, N, k, stride, padding, 0)
+        call("ctu_conv_cin1_fwd", dcode(x.dtype), ptr(x), ptr(wf), ptr(out), g, stream())
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, padding, k, dout)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        stride, padding, k, dout = ctx.cfg
+        gy = gy.contiguous()
+        B, D, H, W, _ = x.shape
+        N = weight.shape[0]
+        taps = k[0] * k[1] * k[2]
+        gw = None
+        if ctx.needs_input_grad[1]:
+            panel = torch.zeros((taps, N), dtype=torch.float32, device=x.device)
+            g = _geom(B, (D, H, W), dout, 8, 0, N, k, stride, padding, 0)
+            call("ctu_conv_cin1_wgrad", dcode(x.dtype), ptr(x), ptr(gy), ptr(panel), g, stream())
+            gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            permute3(panel, gw, (1, N, taps), (0, 1, N), (0, taps, 1))
+        return None, gw, None, None
+
+
+def conv3d_cin1(x, weight, stride, padding):
+    return ConvCin1Fn.apply(x, weight, _t3(stride), _t3(padding))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# normalisation / activation
+# ---------------------------------------------------------------------------------------------------------------
+class InstanceNormFn(torch.autograd.Function):
+    """y = act(InstanceNorm3d(x) + residual), eps 1e-5, no affine, LeakyReLU(0.01)
+    (resnet.py:97-124,156-157,198; hybrid_CTUNet.py:84-104)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, act: bool):
+        _check_act(x)
+        B, C = x.shape[0], x.shape[-1]
+        S = x.numel() // (B * C)
+        stats = torch.zeros((B, C, 2), dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        dc = dcode(x.dtype)
+        call("ctu_in_stats", dc, ptr(x), B, S, C, ptr(stats), stream())
+        call("ctu_in_apply", dc, ptr(x), ptr(stats), ptr(residual), ptr(y), B, S, C, int(act), stream())
+        ctx.save_for_backward(x, y, stats)
+        ctx.act = int(act)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, stats = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, C = x.shape[0], x.shape[-1]
+        S = x.numel() // (B * C)
+        sums = torch.zeros((B, C, 2), dtype=torch.float32, device=x.device)
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if ctx.has_res else None
+        dc = dcode(x.dtype)
+        call("ctu_in_bwd_reduce", dc, ptr(gy), ptr(x), ptr(y), ptr(stats), ptr(sums), B, S, C, ctx.act, stream())
+        call("ctu_in_bwd_apply", dc, ptr(gy), ptr(x), ptr(y), ptr(stats), ptr(sums), ptr(gx), ptr(gres), B, S, C,
+             ctx.act, stream())
+        return gx, gres, None
+
+
+def instance_norm(x, residual=None, act=False):
+    return InstanceNormFn.apply(x, residual, act)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm(dim), eps 1e-5 (vit.py:35,55,116,118; hybrid_CTUNet.py:456,518,630-631)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        _check_act(x)
+        dim = x.shape[-1]
+        rows = x.numel() // dim
+        y = torch.empty_like(x)
+        mr = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        call("ctu_layernorm_fwd", dcode(x.dtype), ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mr), rows, dim, stream())
+        ctx.save_for_backward(x, gamma, mr)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, mr = ctx.saved_tensors
+        gy = gy.contiguous()
+        dim = x.shape[-1]
+        rows = x.numel() // dim
+        gx = torch.empty_like(x)
+        gg = torch.zeros(dim, dtype=torch.float32, device=x.device)
+        gb = torch.zeros(dim, dtype=torch.float32, device=x.device)
+        call("ctu_layernorm_bwd", dcode(x.dtype), ptr(gy), ptr(x), ptr(gamma), ptr(mr), ptr(gx), ptr(gg), ptr(gb), rows,
+             dim, stream())
+        return gx, gg, gb
+
+
+def layer_norm(x, gamma, beta):
+    return LayerNormFn.apply(x, gamma, beta)
+
+
+class AddBcastFn(torch.autograd.Function):
+    """x + pos_embedding (vit.py:133): x [B, n, C], pos fp32 [1, n, C]."""
+
+    @staticmethod
+    def forward(ctx, x, pos):
+        _check_act(x)
+        B = x.shape[0]
+        rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+        y = torch.empty_like(x)
+        call("ctu_add_bcast", dcode(x.dtype), ptr(x), ptr(pos), ptr(y), rows, cols, rows // B, stream())
+        ctx.B = B
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        gp = None
+        if ctx.needs_input_grad[1]:
+            per = gy.numel() // ctx.B
+            gp = torch.zeros((1, *gy.shape[1:]), dtype=torch.float32, device=gy.device)
+            call("ctu_colsum", dcode(gy.dtype), ptr(gy), ctx.B, per, per, ptr(gp), stream())
+        return gy, gp
+
+
+def add_bcast(x, pos):
+    return AddBcastFn.apply(x, pos)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# attention / fusion / layout
+# ---------------------------------------------------------------------------------------------------------------
+class AttentionFn(torch.autograd.Function):
+    """softmax(scale * q k^T + rel_pos_bias) v on a fused qkv matrix (vit.py:66-78; hybrid_CTUNet.py:481-511).
+    qkv: [B, D, H, W, 3*heads*dh] (part 1/2: window partitions of the volume) or [B, n, 3*heads*dh] (part 0)."""
+
+    @staticmethod
+    def forward(ctx, qkv, bias_table, part: int, win: int, heads: int, scale: float):
+        _check_act(qkv)
+        dim = qkv.shape[-1] // 3
+        dh = dim // heads
+        if part == 0:
+            B, n = qkv.shape[0], qkv.shape[1]
+            geo = AttnGeom(0, B, n, 1, 1, 0, heads, dh, scale)
+            groups, ntok = B, n
+        else:
+            B, D, H, W = qkv.shape[:4]
+            geo = AttnGeom(part, B, D, H, W, win, heads, dh, scale)
+            groups, ntok = B * (D // win) * (H // win) * (W // win), win ** 3
+        out = torch.empty((*qkv.shape[:-1], dim), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((groups * heads, ntok), dtype=torch.float32, device=qkv.device)
+        call("ctu_attn_fwd", dcode(qkv.dtype), ptr(qkv), ptr(bias_table), ptr(out), ptr(lse), geo, stream())
+        ctx.save_for_backward(qkv, bias_table, out, lse)
+        ctx.geo = geo
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        qkv, bias_table, out, lse = ctx.saved_tensors
+        gout = gout.contiguous()
+        gqkv = torch.empty_like(qkv)
+        gbias = torch.zeros_like(bias_table) if bias_table is not None else None
+        call("ctu_attn_bwd", dcode(qkv.dtype), ptr(qkv), ptr(bias_table), ptr(out), ptr(gout), ptr(lse), ptr(gqkv),
+             ptr(gbias), ctx.geo, stream())
+        return gqkv, gbias, None, None, None, None
+
+
+def attention(qkv, heads, scale, bias_table=None, part=0, win=0):
+    return AttentionFn.apply(qkv, bias_table, part, win, heads, scale)
+
+
+class PwaFn(torch.autograd.Function):
+    """Binary cross-weight core (hybrid_CTUNet.py:651-665): a1 = sigmoid(scale*(<q2,k1>-<q1,k2>)) per head of 32."""
+
+    @staticmethod
+    def forward(ctx, qkv1, qkv2, scale: float):
+        _check_act(qkv1)
+        C = qkv1.shape[-1] // 3
+        rows = qkv1.numel() // (3 * C)
+        out = torch.empty((*qkv1.shape[:-1], C), dtype=qkv1.dtype, device=qkv1.device)
+        call("ctu_pwa_fwd", dcode(qkv1.dtype), ptr(qkv1), ptr(qkv2), ptr(out), rows, C, scale, stream())
+        ctx.save_for_backward(qkv1, qkv2)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        qkv1, qkv2 = ctx.saved_tensors
+        gout = gout.contiguous()
+        C = qkv1.shape[-1] // 3
+        rows = qkv1.numel() // (3 * C)
+        g1, g2 = torch.empty_like(qkv1), torch.empty_like(qkv2)
+        call("ctu_pwa_bwd", dcode(qkv1.dtype), ptr(qkv1), ptr(qkv2), ptr(gout), ptr(g1), ptr(g2), rows, C, ctx.scale,
+             stream())
+        return g1, g2, None
+
+
+def pwa(qkv1, qkv2, scale):
+    return PwaFn.apply(qkv1, qkv2, scale)
+
+
+class PixelShuffleFn(torch.autograd.Function):
+    """'b (c p1 p2 p3) h w f -> b (h p1) (w p2) (f p3) c' in channels-last form (hybrid_CTUNet.py:420-428)."""
+
+    @staticmethod
+    def forward(ctx, x, factor):
+        _check_act(x)
+        B, D, H, W, Cbig = x.shape
+        p1, p2, p3 = factor
+        c = Cbig // (p1 * p2 * p3)
+        y = torch.empty((B, D * p1, H * p2, W * p3, c), dtype=x.dtype, device=x.device)
+        call("ctu_pixel_shuffle", dcode(x.dtype), ptr(x), ptr(y), B, D, H, W, c, p1, p2, p3, 0, stream())
+        ctx.cfg = (B, D, H, W, c, p1, p2, p3)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        B, D, H, W, c, p1, p2, p3 = ctx.cfg
+        gx = torch.empty((B, D, H, W, c * p1 * p2 * p3), dtype=gy.dtype, device=gy.device)
+        call("ctu_pixel_shuffle", dcode(gy.dtype), ptr(gy), ptr(gx), B, D, H, W, c, p1, p2, p3, 1, stream())
+        return gx, None
+
+
+def pixel_shuffle(x, factor):
+    return PixelShuffleFn.apply(x, tuple(factor))
+
+
+def patchify(x, p1, p2, p3):
+    """x [B, H, W, F] (single channel) -> tokens [B, (H/p1)(W/p2)(F/p3), p1*p2*p3]  (vit.py:115); no gradient."""
+    _check_act(x)
+    B, H, W, Fr = x.shape
+    tok = torch.empty((B, (H // p1) * (W // p2) * (Fr // p3), p1 * p2 * p3), dtype=x.dtype, device=x.device)
+    call("ctu_patchify", dcode(x.dtype), ptr(x), ptr(tok), B, H, W, Fr, p1, p2, p3, stream())
+    return tok
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    call("ctu_cast", ptr(x), dcode(x.dtype), ptr(out), dcode(dtype), x.numel(), stream())
+    return out

@@ -1,0 +1,335 @@
+"""Caller-side counterparts of the reference's training step (trainer_CTUNet.py:76-133, main_CTUNet.py:156-204):
+fused DiceCE with on-device deep-supervision targets, flat fused AdamW, and a one-process-per-GPU data-parallel
+wrapper that all-reduces gradient buckets over RCCL on a side stream while backward is still running.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import ops
+from ._lib import call, dcode, ptr, require_device, stream
+import ctypes as C
+
+# ---------------------------------------------------------------------------------------------------------------
+# DiceCE
+# ---------------------------------------------------------------------------------------------------------------
+_idx_cache: Dict[Tuple, torch.Tensor] = {}
+
+
+def zoom_nearest_index(n_in: int, n_out: int) -> np.ndarray:
+    """Source index of scipy.ndimage.zoom(order=0) along one axis (trainer_CTUNet.py:93-94):
+    floor(i*(n_in-1)/(n_out-1) + 0.5).  NOT a stride-2/4 subsample (96->48 jumps by 3 at i=24)."""
+    if n_out == 1:
+        return np.zeros(1, dtype=np.int32)
+    zoom = float(n_in - 1) / float(n_out - 1)
+    coord = np.arange(n_out, dtype=np.float64) * zoom
+    idx = np.floor(coord + 0.5).astype(np.int32)
+    idx[(coord < 0) | (coord > n_in - 1)] = -1  # scipy: out of range -> cval 0 (e.g. last index of 48->24)
+    return idx
+
+
+def _index_map(n_in: int, n_out: int, device) -> torch.Tensor:
+    key = (n_in, n_out, str(device))
+    t = _idx_cache.get(key)
+    if t is None:
+        t = torch.from_numpy(zoom_nearest_index(n_in, n_out)).to(device)
+        _idx_cache[key] = t
+    return t
+
+
+class DiceCEFn(torch.autograd.Function):
+    """weight * DiceCELoss(to_onehot_y, softmax, squared_pred, smooth_nr, smooth_dr)(logits, zoom(target)).
+    logits: the [B, n_cls, D, H, W] view a model head returns (channels-last storage padded to 16 columns) or any
+    tensor of that shape; target: float class ids [B, 1, LD, LH, LW] at full resolution."""
+
+    @staticmethod
+    def forward(ctx, logits, target, weight: float, smooth_nr: float, smooth_dr: float):
+        require_device(logits)
+        require_device(target)
+        B, n_cls, D, H, W = logits.shape
+        st = logits.stride()
+        padded = (st[1] == 1 and st[4] in (8, 16) and st[4] >= n_cls and st[3] == W * st[4] and st[2] == H * W * st[4]
+                  and st[0] == D * H * W * st[4] and logits.dtype in (torch.float32, torch.bfloat16))
+        if padded:
+            ldl = st[4]
+            buf = logits
+        else:  # repack into the padded channels-last layout (plumbing; the model heads never take this path)
+            ldl = 16
+            dt = logits.dtype if logits.dtype in (torch.float32, torch.bfloat16) else torch.float32
+            tmp = torch.zeros((B, D, H, W, ldl), dtype=dt, device=logits.device)
+            tmp[..., :n_cls] = logits.permute(0, 2, 3, 4, 1)
+            buf = tmp
+        tgt = target.detach()
+        if tgt.dtype != torch.float32:
+            tgt = tgt.float()
+        tgt = tgt.contiguous()
+        LD, LH, LW = tgt.shape[2:]
+        dev = logits.device
+        idx = (_index_map(LD, D, dev), _index_map(LH, H, dev), _index_map(LW, W, dev))
+        acc = torch.zeros(B * n_cls * 3 + 1, dtype=torch.float32, device=dev)
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        dc = dcode(buf.dtype)
+        call("ctu_dicece_fwd", dc, ptr(buf), ldl, ptr(tgt), ptr(idx[0]), ptr(idx[1]), ptr(idx[2]), B, D, H, W, LD, LH,
+             LW, n_cls, ptr(acc), stream())
+        call("ctu_dicece_finalize", ptr(acc), B, n_cls, D * H * W, smooth_nr, smooth_dr, weight, ptr(loss), stream())
+        ctx.save_for_backward(buf, tgt, acc, *idx)
+        ctx.cfg = (B, n_cls, D, H, W, LD, LH, LW, ldl, weight, smooth_nr, smooth_dr, padded, logits.dtype)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        buf, tgt, acc, i0, i1, i2 = ctx.saved_tensors
+        B, n_cls, D, H, W, LD, LH, LW, ldl, weight, nr, dr, padded, in_dtype = ctx.cfg
+        gscale = gloss.detach().float().reshape(1).contiguous()
+        dl = torch.empty((B, D, H, W, ldl), dtype=buf.dtype, device=buf.device)
+        call("ctu_dicece_bwd", dcode(buf.dtype), ptr(buf), ldl, ptr(tgt), ptr(i0), ptr(i1), ptr(i2), B, D, H, W, LD, LH,
+             LW, n_cls, ptr(acc), nr, dr, weight, ptr(gscale), ptr(dl), stream())
+        g = dl[..., :n_cls].permute(0, 4, 1, 2, 3)
+        if not padded:
+            g = g.to(in_dtype)
+        return g, None, None, None, None
+
+
+def dice_ce_loss(logits, target, weight: float = 1.0, smooth_nr: float = 0.0, smooth_dr: float = 1e-6):
+    return DiceCEFn.apply(logits, target, float(weight), float(smooth_nr), float(smooth_dr))
+
+
+def ctunet_loss(outputs, target, smooth_nr=0.0, smooth_dr=1e-6):
+    """trainer_CTUNet.py:92-103: L(o1a,t) + 0.5*(L(o1b,t/2) + 0.5*L(o1c,t/4)) + 0.5*(L(o2a,t) + L(o2b,t)); the
+    nearest-neighbour target downsampling happens inside the loss kernel (no host round trip)."""
+    (o1a, o1b, o1c), (o2a, o2b) = outputs
+    a = (smooth_nr, smooth_dr)
+    return (dice_ce_loss(o1a, target, 1.0, *a) + dice_ce_loss(o1b, target, 0.5, *a) + dice_ce_loss(o1c, target, 0.25, *a)
+            + dice_ce_loss(o2a, target, 0.5, *a) + dice_ce_loss(o2b, target, 0.5, *a))
+
+
+def cunet_loss(outputs, target, smooth_nr=0.0, smooth_dr=1e-6):
+    """trainer_CUNet.py:91-100."""
+    o0, o1, o2 = outputs
+    a = (smooth_nr, smooth_dr)
+    return dice_ce_loss(o0, target, 1.0, *a) + dice_ce_loss(o1, target, 0.5, *a) + dice_ce_loss(o2, target, 0.25, *a)
+
+
+def tunet_loss(outputs, target, smooth_nr=0.0, smooth_dr=1e-6):
+    """trainer_TUNet.py:80-82."""
+    o0, o1 = outputs
+    return dice_ce_loss(o0, target, 1.0, smooth_nr, smooth_dr) + dice_ce_loss(o1, target, 1.0, smooth_nr, smooth_dr)
+
+
+LOSSES = {"ctunet": ctunet_loss, "cunet": cunet_loss, "tunet": tunet_loss}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# flat parameter / gradient storage + fused AdamW
+# ---------------------------------------------------------------------------------------------------------------
+class FlatParams:
+    """Re-homes a model's parameters and gradients into two flat fp32 buffers (64-element aligned segments) so the
+    optimizer is one kernel and gradient all-reduce works on contiguous slices.  ``order`` lets the caller lay
+    parameters out in expected gradient-ready order (buckets then become ready front to back)."""
+
+    ALIGN = 64
+
+    def __init__(self, params: Iterable[nn.Parameter]):
+        self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise TypeError("master parameters must be float32")
+            self.offsets.append(off)
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.total = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                self.flat[o:o + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = self.flat[o:o + p.numel()].view(p.shape)
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        self.touched = [False] * len(self.params)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+        ops.bump_weights_epoch()
+
+    def _make_hook(self, i):
+        def hook(p):
+            self.touched[i] = True
+            # autograd may have replaced .grad (first accumulation into a None grad): fold it back into the flat buffer
+            g = p.grad
+            o = self.offsets[i]
+            view = self.grad[o:o + p.numel()].view(p.shape)
+            if g is not None and g.data_ptr() != view.data_ptr():
+                view.add_(g)
+                p.grad = view
+        return hook
+
+    def zero_grad(self):
+        """Equivalent of `param.grad = None` (trainer_CTUNet.py:88-89) without giving up the flat views."""
+        self.grad.zero_()
+        self.touched = [False] * len(self.params)
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def untouched_ranges(self) -> List[Tuple[int, int]]:
+        out = []
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            if not self.touched[i]:
+                end = o + (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+                if out and out[-1][1] == o:
+                    out[-1] = (out[-1][0], end)
+                else:
+                    out.append((o, end))
+        return out
+
+
+class FusedAdamW:
+    """torch.optim.AdamW(lr, betas, eps, weight_decay) semantics (main_CTUNet.py:192-193) as ONE kernel over the flat
+    buffers.  Parameters whose gradient was never produced in this step (7 ResBlock.conv3 tensors in CTUNet,
+    SURVEY.md section 8a row D) are skipped exactly like torch skips `grad is None`."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, flat: Optional[FlatParams] = None):
+        self.flat = flat if flat is not None else FlatParams(params)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.m = torch.zeros_like(self.flat.flat)
+        self.v = torch.zeros_like(self.flat.flat)
+        self.step_count = 0
+        self.param_groups = [{"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]
+        self._static_skip = None
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat.zero_grad()
+
+    def freeze_skip_ranges(self):
+        """After one real backward: remember which parameters never receive a gradient, so later steps (e.g. replayed
+        from a HIP graph, where Python hooks do not run) skip the same ranges."""
+        self._static_skip = self.flat.untouched_ranges()
+        return self._static_skip
+
+    def step(self):
+        self.step_count += 1
+        skip = self._static_skip if self._static_skip is not None else self.flat.untouched_ranges()
+        if len(skip) > 16:
+            raise RuntimeError(f"{len(skip)} disjoint gradient-less parameter ranges; the fused AdamW handles up to 16")
+        arr = (C.c_int64 * (2 * max(1, len(skip))))()
+        for k, (a, b) in enumerate(skip):
+            arr[2 * k], arr[2 * k + 1] = a, b
+        f = self.flat
+        lr = self.param_groups[0]["lr"]
+        call("ctu_adamw", ptr(f.flat), ptr(f.grad), ptr(self.m), ptr(self.v), f.total, lr, self.betas[0], self.betas[1],
+             self.eps, self.weight_decay, self.step_count, arr, len(skip), stream())
+        ops.bump_weights_epoch()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# data parallel: one process per GPU, bucketed gradient all-reduce over RCCL/xGMI overlapped with backward
+# ---------------------------------------------------------------------------------------------------------------
+class DataParallel(nn.Module):
+    """Replacement for DistributedDataParallel(find_unused_parameters=True) at main_CTUNet.py:187-189.
+
+    Gradients live in one flat buffer (FlatParams) laid out in *expected ready order*; the buffer is cut into
+    buckets of ~bucket_mb.  A post-accumulate hook counts arrivals per bucket; when a bucket is complete its slice is
+    all-reduced (SUM, pre-scaled by 1/world) on a side stream fenced by events, so communication overlaps the rest of
+    backward.  `finish()` (called by the optimizer wrapper / step function) flushes buckets that hold never-touched
+    parameters and makes the compute stream wait for the side stream.  Exposes `.module` like DDP
+    (trainer_CTUNet.py:309 unwraps it).  Works with any backend: "nccl" (= RCCL) on GPUs, "gloo" in CPU tests."""
+
+    def __init__(self, module: nn.Module, flat: Optional[FlatParams] = None, bucket_mb: float = 32.0,
+                 process_group=None, ready_order: Optional[Sequence[nn.Parameter]] = None, broadcast: bool = True):
+        super().__init__()
+        self.module = module
+        self.pg = process_group
+        self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
+        params = list(ready_order) if ready_order is not None else [p for p in module.parameters() if p.requires_grad]
+        self.flat = flat if flat is not None else FlatParams(params)
+        f = self.flat
+        # bucket boundaries on parameter boundaries
+        target = int(bucket_mb * 1024 * 1024 / 4)
+        self.buckets: List[Tuple[int, int, List[int]]] = []  # (begin, end, param indices)
+        begin, members = 0, []
+        for i, (p, o) in enumerate(zip(f.params, f.offsets)):
+            members.append(i)
+            end = f.offsets[i + 1] if i + 1 < len(f.params) else f.total
+            if end - begin >= target or i + 1 == len(f.params):
+                self.buckets.append((begin, end, members))
+                begin, members = end, []
+        self._bucket_of = {}
+        for b, (_, _, mem) in enumerate(self.buckets):
+            for i in mem:
+                self._bucket_of[i] = b
+        self._pending = [len(mem) for _, _, mem in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+        self._is_cuda = f.flat.is_cuda
+        self._side = torch.cuda.Stream() if self._is_cuda else None
+        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(f.params)]
+        if broadcast and self.world > 1:
+            dist.broadcast(f.flat, src=0, group=self.pg)  # DDP ctor semantics: rank 0's parameters win
+            ops.bump_weights_epoch()
+
+    def forward(self, *a, **kw):
+        return self.module(*a, **kw)
+
+    def _make_hook(self, i):
+        def hook(p):
+            b = self._bucket_of[i]
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        if self._launched[b] or self.world == 1:
+            self._launched[b] = True
+            return
+        self._launched[b] = True
+        begin, end, _ = self.buckets[b]
+        sl = self.flat.grad[begin:end]
+        if self._is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                sl.mul_(1.0 / self.world)
+                dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg)
+        else:
+            sl.mul_(1.0 / self.world)
+            self._works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def finish(self):
+        """Call after backward, before the optimizer step."""
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b)  # buckets containing parameters that never produced a gradient
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self._is_cuda and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._pending = [len(mem) for _, _, mem in self.buckets]
+        self._launched = [False] * len(self.buckets)
+
+
+def gradient_ready_order(model: nn.Module) -> List[nn.Parameter]:
+    """Parameters in the order autograd finishes them for CTUNet/CUNet/TUNet (measured on the
+    reference): res heads -> res decoders 0..3 -> convnet (deep to shallow) -> vit heads/decoder -> vit_encoder ->
+    vit_encoder0 -> vit.  Modules not present are skipped; anything unlisted goes last."""
+    prefixes = ["res_out_24x24", "res_out_48x48", "res_out", "res_decoder0", "res_decoder1", "res_decoder2",
+                "res_decoder3", "convnet.layer4", "convnet.layer3", "convnet.layer2", "convnet.layer1", "convnet",
+                "decoder_linear_96x96", "vit_out", "vit_decoder0", "vit_encoder.", "vit_encoder0", "vit."]
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    taken, out = set(), []
+    for pre in prefixes:
+        for n, p in reversed(named):
+            if n not in taken and n.startswith(pre):
+                taken.add(n)
+                out.append(p)
+    out += [p for n, p in named if n not in taken]
+    return out

@@ -5,7 +5,7 @@
  * (networks/hybrid_CTUNet.py:694-1036).  Every FLOP there is dispatched through ATen leaf ops; this header
  * declares the native entry points that replace those leaf-op families, one group per row of SURVEY.md
  * section 2.2 (K1..K15).  Each declaration cites the reference call sites it stands in for.  The host-side
- * mirror (hybrid-ctunet_amd/networks/*.py) binds these with ctypes (INTEGRATION.md shows the stub).
+ * mirror (the Python files under hybrid-ctunet_amd/networks) binds these with ctypes (INTEGRATION.md shows the stub).
  *
  * Conventions
  *   - plain pointers and sizes only; no torch types.  All pointers are DEVICE pointers unless noted.
@@ -86,7 +86,7 @@ int ctu_igemm_tn(ctu_dtype dtype, const void* p, int32_t ldp, const void* q1, co
                  const ctu_geom* g, ctu_stream_t stream);
 
 /* Cin == 1 convolutions (vit_encoder0.conv1 1->64 3x3x3, hybrid_CTUNet.py:57-65; ResNet stem 7x7x7 s(2,2,1),
- * resnet.py:150-155).  x: [B][Di][Hi][Wi] ; w: fp32 [taps][N] ; out: [M][N].  kernel 3x3x3 or 7x7x7 only. */
+ * resnet.py:150-155).  x: [B][Di][Hi][Wi] ; w: fp32 [taps][N] ; out: [M][N].  kernel 1x1x1 (ResBlock.conv3 shortcut), 3x3x3 or 7x7x7. */
 int ctu_conv_cin1_fwd(ctu_dtype dtype, const void* x, const float* w, void* out, const ctu_geom* g,
                       ctu_stream_t stream);
 int ctu_conv_cin1_wgrad(ctu_dtype dtype, const void* x, const void* dy, float* dw, const ctu_geom* g,

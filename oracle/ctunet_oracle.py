@@ -642,8 +642,14 @@ def zoom_nearest_index(n_in: int, n_out: int) -> np.ndarray:
     (checked against scipy in tests)."""
     if n_out == 1:
         return np.zeros(1, dtype=np.int64)
-    i = np.arange(n_out, dtype=np.float64)
-    return np.floor(i * (n_in - 1) / (n_out - 1) + 0.5).astype(np.int64)
+    # scipy computes coordinate = i * zoom with zoom = (n_in-1)/(n_out-1) in double; a coordinate that rounds to
+    # slightly more than n_in-1 (e.g. 48->24: 23*(47/23) = 47.00000000000001) is OUT of range and yields cval=0.
+    # Such positions are returned as -1 ("constant 0").  96->48 and 96->24 (the trainer's cases) have none.
+    zoom = float(n_in - 1) / float(n_out - 1)
+    coord = np.arange(n_out, dtype=np.float64) * zoom
+    idx = np.floor(coord + 0.5).astype(np.int64)
+    idx[(coord < 0) | (coord > n_in - 1)] = -1
+    return idx
 
 
 def downsample_target(target: torch.Tensor, zoom: Sequence[float]) -> torch.Tensor:
@@ -653,7 +659,12 @@ def downsample_target(target: torch.Tensor, zoom: Sequence[float]) -> torch.Tens
         n_in = target.shape[ax]
         n_out = int(round(n_in * z))
         idx = torch.from_numpy(zoom_nearest_index(n_in, n_out)).to(target.device)
-        out = out.index_select(ax, idx)
+        sel = out.index_select(ax, idx.clamp(min=0))
+        if (idx < 0).any():  # scipy's out-of-range positions read cval = 0
+            shape = [1] * out.dim()
+            shape[ax] = -1
+            sel = sel * (idx >= 0).to(sel.dtype).view(shape)
+        out = sel
     return out
 
 

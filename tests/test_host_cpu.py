@@ -1,0 +1,179 @@
+"""CPU suite, part 2: the C-ABI library loads and exports every symbol include/ctunet_hip.h declares (no compute calls
+without a GPU), the host-side mirror keeps the reference's interface (state_dict manifests, constructor errors, loud
+failure without a HIP device), and the data-parallel wrapper all-reduces correctly over gloo with world_size 2."""
+import ctypes
+import json
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import hybrid_ctunet_amd as H
+from hybrid_ctunet_amd import _lib, train
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ctunet_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(ctu_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 28
+    path = _lib.build()  # no-op when the in-tree .so is newer than its sources
+    lib = ctypes.CDLL(path)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in ctunet_hip.h but not exported"
+    assert sorted(_lib.EXPORTED) == declared, "python binding table and header disagree"
+    lib.ctu_abi_version.restype = ctypes.c_int
+    assert lib.ctu_abi_version() == 1
+
+
+def test_ctypes_struct_layouts_match_header():
+    # 20 int32 fields; epilogue: 2 pointers, 2 ints, pointer, 10 ints
+    assert ctypes.sizeof(_lib.Geom) == 80
+    assert ctypes.sizeof(_lib.AttnGeom) == 36
+    e = _lib.Epilogue
+    assert e.bias.offset == 0 and e.residual.offset == 8 and e.act.offset == 16 and e.ldc.offset == 20
+    assert e.out2.offset == 24 and e.n_split.offset == 32 and e.sc_kw.offset == 32 + 4 * 9
+    assert ctypes.sizeof(e) == 72
+
+
+@pytest.mark.parametrize("kind,depth,man", [("ctunet", 101, "ctunet101"), ("cunet", 101, "cunet101"),
+                                            ("cunet", 50, "cunet50"), ("tunet", 101, "tunet")])
+def test_state_dict_keys_and_shapes_match_reference_manifest(golden_dir, kind, depth, man):
+    with torch.device("meta"):
+        m = H.build_model(kind, model_depth=depth)
+    ref = json.load(open(os.path.join(golden_dir, f"manifest_{man}.json")))
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == ref
+    assert len(list(m.buffers())) == (6 if kind != "cunet" else 0)  # rel_pos_indices, non-persistent
+
+
+def test_constructor_contract():
+    with pytest.raises(AssertionError):
+        H.CUNet(out_channels=14, model_depth=34)
+    with torch.device("meta"):
+        with pytest.raises(ValueError):
+            H.CTUNet(in_channels=1, dim_conv_stem=64, out_channels=14, model_depth=50, img_size=(96, 96), frames=96,
+                     patch_frame=16)
+        with pytest.raises(NotImplementedError):
+            H.CUNet(out_channels=14, model_depth=50, norm_name="batch")
+        with pytest.raises(NotImplementedError):
+            H.TUNet(in_channels=1, dim_conv_stem=64, out_channels=14, img_size=(96, 96), frames=96, patch_frame=8,
+                    dropout_rate=0.2)
+        with pytest.raises(AssertionError):  # vit.py:108-109
+            H.TUNet(in_channels=1, dim_conv_stem=64, out_channels=14, img_size=(100, 96), frames=96, patch_frame=8)
+
+
+def test_no_cpu_fallback():
+    m = H.CUNet(out_channels=14, model_depth=50)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 96, 96, 96))
+    with pytest.raises(RuntimeError):
+        H.dice_ce_loss(torch.zeros(1, 14, 4, 4, 4), torch.zeros(1, 1, 4, 4, 4))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "hybrid-ctunet_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_zoom_index_map_host_equals_oracle():
+    from oracle import ctunet_oracle as O
+    for n_in, n_out in ((96, 48), (96, 24), (48, 24), (24, 12), (10, 5)):
+        assert np.array_equal(train.zoom_nearest_index(n_in, n_out), O.zoom_nearest_index(n_in, n_out))
+    a = train.zoom_nearest_index(96, 48)
+    assert a[23] == 46 and a[24] == 49  # the jump SURVEY 8a-H documents: not a stride-2 subsample
+
+
+def test_gradient_ready_order_covers_all_parameters():
+    with torch.device("meta"):
+        m = H.build_model("ctunet")
+    order = train.gradient_ready_order(m)
+    assert len(order) == 412 and len({id(p) for p in order}) == 412
+    names = {id(p): n for n, p in m.named_parameters()}
+    first, last = names[id(order[0])], names[id(order[-1])]
+    assert first.startswith("res_out_24x24") and last.startswith("vit.")
+
+
+class _Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(12, 40)
+        self.unused = nn.Linear(3, 3)  # never receives a gradient (like ResBlock.conv3 when in == out)
+        self.b = nn.Linear(40, 5)
+
+    def forward(self, x):
+        return self.b(torch.tanh(self.a(x)))
+
+
+def test_flat_params_views_and_untouched_ranges():
+    torch.manual_seed(0)
+    m = _Toy()
+    ref = [p.detach().clone() for p in m.parameters()]
+    fp = train.FlatParams(m.parameters())
+    for p, r in zip(m.parameters(), ref):
+        assert torch.equal(p, r) and p.data_ptr() >= fp.flat.data_ptr()
+    m(torch.randn(7, 12)).sum().backward()
+    rng = fp.untouched_ranges()
+    assert len(rng) == 1 and rng[0][1] - rng[0][0] == 64 + 64  # weight (9->64) + bias (3->64) of `unused`
+    assert fp.grad.abs().sum() > 0
+    for p, o in zip(fp.params, fp.offsets):
+        assert p.grad.data_ptr() == fp.grad.data_ptr() + 4 * o
+    fp.zero_grad()
+    assert fp.grad.abs().sum() == 0 and fp.untouched_ranges()[0][0] == 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(123 + rank)  # different init per rank: the wrapper must broadcast rank 0's parameters
+    m = _Toy()
+    dp = train.DataParallel(m, bucket_mb=0.0005)  # tiny buckets -> several of them
+    assert hasattr(dp, "module") and len(dp.buckets) >= 2
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 12, generator=g)
+    xs = x[rank * 4:(rank + 1) * 4]
+    for step in range(2):
+        dp.flat.zero_grad()
+        dp(xs).pow(2).mean().backward()
+        dp.finish()
+    torch.save({"grad": dp.flat.grad.clone(), "flat": dp.flat.flat.clone()}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "r0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "r1.pt"))
+    assert torch.equal(r0["flat"], r1["flat"])            # parameters were broadcast from rank 0
+    assert torch.allclose(r0["grad"], r1["grad"], atol=1e-7)  # every bucket (incl. the one with unused params) reduced
+    # reference: single process, full batch, rank 0's init
+    torch.manual_seed(123)
+    m = _Toy()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 12, generator=g)
+    # mean over the 2 half-batches of the per-half mean loss == what DP averages
+    loss = 0.5 * (m(x[:4]).pow(2).mean() + m(x[4:]).pow(2).mean())
+    loss.backward()
+    ref = torch.cat([torch.nn.functional.pad(p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel()),
+                                             (0, (-p.numel()) % 64)) for p in m.parameters()])
+    assert torch.allclose(r0["grad"], ref, atol=1e-6)

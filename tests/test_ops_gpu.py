@@ -1,0 +1,369 @@
+"""GPU parity, op level: every HIP kernel family (called through the C ABI via hybrid_ctunet_amd.ops) against a plain
+PyTorch float64 CPU computation of the same op on the same seeded inputs.  Tolerances: fp32 mode 2e-4 of the
+reference's max magnitude (exact-f32 MFMA, different summation order); bf16 mode 3e-2 (8-bit mantissa operands)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-4, torch.bfloat16: 3e-2}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import hybrid_ctunet_amd  # noqa: F401
+    from hybrid_ctunet_amd import ops as o
+    return o
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return ((torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * scale)
+
+
+def dev(t, dtype, grad=False):
+    """CPU float64 -> device tensor of `dtype`; returns (device tensor, the float64 value it actually holds)."""
+    d = t.to(dtype).cuda().contiguous()
+    held = d.detach().cpu().double()
+    if grad:
+        d.requires_grad_(True)
+    return d, held
+
+
+def close(got, ref, dtype, what="", scale=None):
+    got = got.detach().float().cpu().double()
+    ref = ref.detach().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    s = ref.abs().max().item() if scale is None else scale
+    err = (got - ref).abs().max().item()
+    assert math.isfinite(err) and err <= TOL[dtype] * max(s, 1e-6), f"{what}: max|d|={err:.3e} ref max={s:.3e} ({dtype})"
+
+
+def cl(t):  # NCDHW -> NDHWC
+    return t.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def cf(t):  # NDHWC -> NCDHW
+    return t.permute(0, 4, 1, 2, 3).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,K,N,bias,act,res", [(300, 96, 72, True, 0, False), (257, 32, 136, True, 1, True),
+                                                (1000, 768, 64, False, 0, True), (130, 16, 16, True, 0, False),
+                                                (64, 3072, 768, True, 1, False)])
+def test_linear(ops, dtype, M, K, N, bias, act, res):
+    x, xh = dev(rnd((M, K), 1), dtype, True)
+    w, wh = dev(rnd((N, K), 2, 1 / math.sqrt(K)), torch.float32, True)
+    b, bh = dev(rnd((N,), 3), torch.float32, True) if bias else (None, None)
+    r, rh = dev(rnd((M, N), 4), dtype, True) if res else (None, None)
+    gy, gyh = dev(rnd((M, N), 5), dtype)
+    y = ops.linear(x, w, b, r, act)
+    wq = wh if dtype == torch.float32 else wh.to(dtype).double()
+    xr, wr = xh.clone().requires_grad_(True), wq.clone().requires_grad_(True)
+    ref = xr @ wr.t()
+    br = rr = None
+    if bias:
+        br = bh.clone().requires_grad_(True)
+        ref = ref + br
+    if act:
+        ref = F.gelu(ref)
+    if res:
+        rr = rh.clone().requires_grad_(True)
+        ref = ref + rr
+    close(y, ref, dtype, "y")
+    y.backward(gy)
+    ref.backward(gyh)
+    close(x.grad, xr.grad, dtype, "gx")
+    close(w.grad, wr.grad, dtype, "gw")
+    if bias:
+        close(b.grad, br.grad, dtype, "gb")
+    if res:
+        close(r.grad, rr.grad, dtype, "gres")
+
+
+CONV_CASES = [  # B, D,H,W, C1, C2, N, k, s, p
+    (2, 5, 6, 7, 32, 0, 64, 3, 1, 1),
+    (1, 6, 8, 10, 32, 32, 48, 3, 1, 1),
+    (1, 8, 8, 6, 64, 0, 32, 3, 2, 1),
+    (1, 8, 6, 8, 64, 0, 136, 1, 2, 0),
+    (2, 4, 5, 6, 64, 64, 32, 1, 1, 0),
+    (1, 9, 10, 11, 16, 0, 24, 3, 1, 1),
+    (1, 8, 8, 8, 32, 0, 32, 3, (2, 2, 1), 1),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d(ops, dtype, case):
+    B, D, H, W, C1, C2, N, k, s, p = case
+    x1, x1h = dev(cl(rnd((B, C1, D, H, W), 1)), dtype, True)
+    x2 = x2h = None
+    if C2:
+        x2, x2h = dev(cl(rnd((B, C2, D, H, W), 2)), dtype, True)
+    w, wh = dev(rnd((N, C1 + C2, k, k, k), 3, 1 / math.sqrt((C1 + C2) * k ** 3)), torch.float32, True)
+    y = ops.conv3d(x1, w, s, p, x2)
+    wq = wh if dtype == torch.float32 else wh.to(dtype).double()
+    xr1 = cf(x1h).requires_grad_(True)
+    xr2 = cf(x2h).requires_grad_(True) if C2 else None
+    wr = wq.clone().requires_grad_(True)
+    xin = torch.cat((xr1, xr2), 1) if C2 else xr1
+    ref = F.conv3d(xin, wr, stride=s, padding=p)
+    close(y, cl(ref), dtype, "y")
+    gy, gyh = dev(cl(rnd(tuple(ref.shape), 4)), dtype)
+    y.backward(gy)
+    ref.backward(cf(gyh))
+    close(x1.grad, cl(xr1.grad), dtype, "gx1")
+    if C2:
+        close(x2.grad, cl(xr2.grad), dtype, "gx2")
+    close(w.grad, wr.grad, dtype, "gw")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("k", [(2, 2, 2), (2, 2, 1)])
+def test_conv_transpose(ops, dtype, k):
+    B, D, H, W, Ci, Co = 2, 3, 4, 5, 64, 32
+    x, xh = dev(cl(rnd((B, Ci, D, H, W), 1)), dtype, True)
+    w, wh = dev(rnd((Ci, Co, *k), 2, 1 / math.sqrt(Ci)), torch.float32, True)
+    y = ops.conv_transpose3d(x, w)
+    wq = wh if dtype == torch.float32 else wh.to(dtype).double()
+    xr, wr = cf(xh).requires_grad_(True), wq.clone().requires_grad_(True)
+    ref = F.conv_transpose3d(xr, wr, stride=k)
+    close(y, cl(ref), dtype, "y")
+    gy, gyh = dev(cl(rnd(tuple(ref.shape), 3)), dtype)
+    y.backward(gy)
+    ref.backward(cf(gyh))
+    close(x.grad, cl(xr.grad), dtype, "gx")
+    close(w.grad, wr.grad, dtype, "gw")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("k,s,p,dims", [((3, 3, 3), (1, 1, 1), (1, 1, 1), (9, 10, 12)), ((7, 7, 7), (2, 2, 1), (3, 3, 3), (12, 14, 10)),
+                                        ((1, 1, 1), (1, 1, 1), (0, 0, 0), (5, 6, 7))])
+def test_conv_cin1(ops, dtype, k, s, p, dims):
+    B, N = 2, 64
+    x, xh = dev(rnd((B, *dims, 1), 1), dtype)
+    w, wh = dev(rnd((N, 1, *k), 2, 1 / math.sqrt(k[0] * k[1] * k[2])), torch.float32, True)
+    y = ops.conv3d_cin1(x, w, s, p)
+    xr, wr = cf(xh), wh.clone().requires_grad_(True)
+    ref = F.conv3d(xr, wr, stride=s, padding=p)
+    close(y, cl(ref), dtype, "y")
+    gy, gyh = dev(cl(rnd(tuple(ref.shape), 3)), dtype)
+    y.backward(gy)
+    ref.backward(cf(gyh))
+    close(w.grad, wr.grad, dtype, "gw")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("C,act,res", [(16, True, False), (64, True, True), (32, False, False), (96, True, True), (1024, False, True)])
+def test_instance_norm(ops, dtype, C, act, res):
+    B, D, H, W = 2, 5, 6, 7
+    x, xh = dev(cl(rnd((B, C, D, H, W), 1, 2.0) + 0.3), dtype, True)
+    r, rh = dev(cl(rnd((B, C, D, H, W), 2)), dtype, True) if res else (None, None)
+    y = ops.instance_norm(x, r, act)
+    xr = cf(xh).requires_grad_(True)
+    ref = F.instance_norm(xr, eps=1e-5)
+    rr = None
+    if res:
+        rr = cf(rh).requires_grad_(True)
+        ref = ref + rr
+    if act:
+        ref = F.leaky_relu(ref, 0.01)
+    close(y, cl(ref), dtype, "y")
+    gy, gyh = dev(cl(rnd((B, C, D, H, W), 3)), dtype)
+    y.backward(gy)
+    ref.backward(cf(gyh))
+    close(x.grad, cl(xr.grad), dtype, "gx")
+    if res:
+        close(r.grad, cl(rr.grad), dtype, "gres")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,dim", [(50, 32), (100, 64), (333, 128), (77, 768), (33, 2048), (40, 512)])
+def test_layer_norm(ops, dtype, rows, dim):
+    x, xh = dev(rnd((rows, dim), 1, 2.0) + 0.2, dtype, True)
+    g, gh = dev(1 + 0.1 * rnd((dim,), 2), torch.float32, True)
+    b, bh = dev(0.1 * rnd((dim,), 3), torch.float32, True)
+    y = ops.layer_norm(x, g, b)
+    xr, gr, br = xh.clone().requires_grad_(True), gh.clone().requires_grad_(True), bh.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (dim,), gr, br, 1e-5)
+    close(y, ref, dtype, "y")
+    gy, gyh = dev(rnd((rows, dim), 4), dtype)
+    y.backward(gy)
+    ref.backward(gyh)
+    close(x.grad, xr.grad, dtype, "gx")
+    close(g.grad, gr.grad, dtype, "ggamma")
+    close(b.grad, br.grad, dtype, "gbeta")
+
+
+def _attn_ref(qkv, heads, scale, bias=None):
+    # qkv: [G, n, 3*dim] float64
+    G, n, d3 = qkv.shape
+    dim = d3 // 3
+    q, k, v = (t.reshape(G, n, heads, dim // heads).transpose(1, 2) for t in qkv.chunk(3, -1))
+    sim = (q @ k.transpose(-1, -2)) * scale
+    if bias is not None:
+        sim = sim + bias
+    return (torch.softmax(sim, -1) @ v).transpose(1, 2).reshape(G, n, dim)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,n,heads,dh", [(2, 50, 2, 32), (1, 432, 3, 64), (2, 130, 2, 64)])
+def test_attention_global(ops, dtype, B, n, heads, dh):
+    dim = heads * dh
+    qkv, qh = dev(rnd((B, n, 3 * dim), 1), dtype, True)
+    scale = dh ** -0.5
+    y = ops.attention(qkv, heads, scale)
+    qr = qh.clone().requires_grad_(True)
+    ref = _attn_ref(qr, heads, scale)
+    close(y, ref, dtype, "y")
+    gy, gyh = dev(rnd((B, n, dim), 2), dtype)
+    y.backward(gy)
+    ref.backward(gyh)
+    close(qkv.grad, qr.grad, dtype, "gqkv")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("part", [1, 2])
+def test_attention_window(ops, dtype, part):
+    from oracle import ctunet_oracle as O
+    B, D, H, W, heads, dh, win = 1, 6, 12, 12, 2, 32, 6
+    dim = heads * dh
+    qkv, qh = dev(rnd((B, D, H, W, 3 * dim), 1), dtype, True)
+    table, th = dev(rnd(((2 * win - 1) ** 3, heads), 2, 0.5), torch.float32, True)
+    scale = dh ** -0.5
+    y = ops.attention(qkv, heads, scale, table, part, win)
+    mode = "block" if part == 1 else "grid"
+    qr, tr = qh.clone().requires_grad_(True), th.clone().requires_grad_(True)
+    xp = O._partition(qr.permute(0, 4, 1, 2, 3), win, mode)  # b X Y Z w1 w2 w3 c
+    b, X, Y, Z = xp.shape[:4]
+    bias = tr[O.rel_pos_indices(win)].permute(2, 0, 1)
+    o = _attn_ref(xp.reshape(b * X * Y * Z, win ** 3, 3 * dim), heads, scale, bias)
+    ref = O._unpartition(o.reshape(b, X, Y, Z, win, win, win, dim), mode).permute(0, 2, 3, 4, 1)
+    close(y, ref, dtype, "y")
+    gy, gyh = dev(rnd((B, D, H, W, dim), 3), dtype)
+    y.backward(gy)
+    ref.backward(gyh)
+    close(qkv.grad, qr.grad, dtype, "gqkv")
+    close(table.grad, tr.grad, dtype, "gbias")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_pwa(ops, dtype):
+    rows, C = 203, 64
+    scale = 32 ** -0.5
+    a, ah = dev(rnd((rows, 3 * C), 1), dtype, True)
+    b, bh = dev(rnd((rows, 3 * C), 2), dtype, True)
+    y = ops.pwa(a, b, scale)
+    ar, br = ah.clone().requires_grad_(True), bh.clone().requires_grad_(True)
+    q1, k1, v1 = (t.reshape(rows, C // 32, 32) for t in ar.chunk(3, -1))
+    q2, k2, v2 = (t.reshape(rows, C // 32, 32) for t in br.chunk(3, -1))
+    d1 = (q2 * k1).sum(-1, keepdim=True) * scale
+    d2 = (q1 * k2).sum(-1, keepdim=True) * scale
+    att = torch.softmax(torch.cat((d1, d2), -1), -1)
+    ref = (att[..., 0:1] * v1 + att[..., 1:2] * v2).reshape(rows, C)
+    close(y, ref, dtype, "y")
+    gy, gyh = dev(rnd((rows, C), 3), dtype)
+    y.backward(gy)
+    ref.backward(gyh)
+    close(a.grad, ar.grad, dtype, "g1")
+    close(b.grad, br.grad, dtype, "g2")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("f,c", [((2, 2, 2), 8), ((2, 2, 1), 16)])
+def test_pixel_shuffle_and_patchify(ops, dtype, f, c):
+    from oracle import ctunet_oracle as O
+    B, D, H, W = 2, 3, 4, 5
+    Cb = c * f[0] * f[1] * f[2]
+    x, xh = dev(cl(rnd((B, Cb, D, H, W), 1)), dtype, True)
+    y = ops.pixel_shuffle(x, f)
+    xr = cf(xh).requires_grad_(True)
+    ps = O.PixelShuffle(f, Cb, c)
+    xx = xr.reshape(B, c, *f, D, H, W).permute(0, 5, 2, 6, 3, 7, 4, 1).reshape(B, D * f[0], H * f[1], W * f[2], c)
+    close(y, xx, dtype, "y")
+    gy, gyh = dev(rnd(tuple(xx.shape), 2), dtype)
+    y.backward(gy)
+    xx.backward(gyh)
+    close(x.grad, cl(xr.grad), dtype, "gx")
+    img, ih = dev(rnd((2, 32, 32, 16), 3), dtype)
+    tok = ops.patchify(img, 16, 16, 8)
+    vit = O.ViT((32, 32), 16, 16, 8, 64, 1, 2, 128, dim_head=32)
+    close(tok, vit.patchify(ih[:, None]), dtype, "patchify")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_add_bcast_and_cast(ops, dtype):
+    x, xh = dev(rnd((3, 20, 64), 1), dtype, True)
+    p, ph = dev(rnd((1, 20, 64), 2), torch.float32, True)
+    y = ops.add_bcast(x, p)
+    close(y, xh + ph, dtype, "y")
+    gy, gyh = dev(rnd((3, 20, 64), 3), dtype)
+    y.backward(gy)
+    close(x.grad, gyh, dtype, "gx")
+    close(p.grad, gyh.sum(0, keepdim=True), dtype, "gpos")
+    f = torch.rand(1000, device="cuda")
+    assert torch.equal(ops.cast(f, torch.bfloat16), f.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape,tshape,weight", [((2, 14, 6, 8, 10), (6, 8, 10), 1.0), ((1, 14, 12, 12, 24), (24, 24, 24), 0.5),
+                                                 ((2, 14, 6, 6, 12), (24, 24, 24), 0.25)])
+def test_dice_ce(ops, dtype, shape, tshape, weight):
+    from oracle import ctunet_oracle as O
+    from hybrid_ctunet_amd.train import dice_ce_loss
+    B, n_cls = shape[0], shape[1]
+    lg64 = rnd(shape, 1, 3.0)
+    # the head layout: channels-last, padded to 16 columns
+    buf = torch.zeros((B, *shape[2:], 16), dtype=dtype, device="cuda")
+    buf[..., :n_cls] = cl(lg64).to(dtype).cuda()
+    buf.requires_grad_(True)
+    view = buf[..., :n_cls].permute(0, 4, 1, 2, 3)
+    g = torch.Generator().manual_seed(7)
+    tgt = torch.randint(0, n_cls, (B, 1, *tshape), generator=g).float()
+    loss = dice_ce_loss(view, tgt.cuda(), weight)
+    held = cf(buf.detach()[..., :n_cls].cpu().double()).requires_grad_(True)
+    zoom = tuple(o / i for o, i in zip(shape[2:], tshape))
+    ref = weight * O.dice_ce_loss(held, O.downsample_target(tgt, zoom))
+    assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item()), (loss.item(), ref.item())
+    (loss * 1.5).backward()
+    (ref * 1.5).backward()
+    close(buf.grad[..., :n_cls], cl(held.grad), dtype, "dlogits")
+    assert buf.grad[..., n_cls:].abs().max().item() == 0.0
+    # non-padded input path (plain contiguous NCDHW logits)
+    plain = cf(buf.detach()[..., :n_cls]).contiguous().requires_grad_(True)
+    loss2 = dice_ce_loss(plain, tgt.cuda(), weight)
+    assert abs(loss2.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    loss2.backward()
+    close(plain.grad, held.grad / 1.5, dtype, "dlogits-plain")
+
+
+def test_fused_adamw_matches_torch(ops):
+    from hybrid_ctunet_amd.train import FusedAdamW
+    torch.manual_seed(0)
+    shapes = [(33, 7), (128,), (5, 3, 3, 3, 3), (1000,), (17,)]
+    ps = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt = FusedAdamW(ps, lr=1e-2, weight_decay=1e-2)
+    ropt = torch.optim.AdamW(ref, lr=1e-2, weight_decay=1e-2)
+    for step in range(4):
+        opt.zero_grad()
+        for r in ref:
+            r.grad = None
+        for i, (p, r) in enumerate(zip(ps, ref)):
+            if i == 2:
+                continue  # never produces a gradient -> must be skipped like torch skips grad=None
+            g = torch.randn(p.shape, device="cuda")
+            (p * g).sum().backward()
+            r.grad = g.clone()
+        opt.step()
+        ropt.step()
+        for p, r in zip(ps, ref):
+            assert torch.allclose(p, r, rtol=1e-5, atol=1e-6), step
