@@ -37,12 +37,20 @@ FLOP_PER_VOLUME = {"ctunet": 10.26e12, "cunet": 5.278e12, "tunet": 3.496e12}  # 
 class KernelTimer:
     """Collects (entry point, algorithmic FLOPs, event pair) for every implicit-GEMM launch."""
 
-    names = {"ctu_igemm_nt", "ctu_igemm_tn"}
+    names = {"ctu_igemm_nt", "ctu_igemm_tn", "ctu_conv3_halo", "ctu_conv3_halo_wgrad"}
 
     def __init__(self):
         self.rec = []
 
     def add(self, name, args, e0, e1):
+        if name == "ctu_conv3_halo":       # (dtype, x1, x2, w, out, out2, B, D, H, W, C1, C2, N, ...)
+            B, D, H, W, C1, C2, N = args[6:13]
+            self.rec.append((name, 2.0 * B * D * H * W * N * (C1 + C2) * 27, e0, e1))
+            return
+        if name == "ctu_conv3_halo_wgrad":  # (dtype, dy, x1, x2, dw, B, D, H, W, C1, C2, N, stream)
+            B, D, H, W, C1, C2, N = args[5:12]
+            self.rec.append((name, 2.0 * B * D * H * W * N * (C1 + C2) * 27, e0, e1))
+            return
         g = args[5] if name == "ctu_igemm_nt" else args[6]
         taps = g.kd * g.kh * g.kw
         rows_out = g.B * g.Do * g.Ho * g.Wo
@@ -201,7 +209,11 @@ def main():
         if roofline is not None:
             res["roofline"] = roofline
         if world == 1 and not a.no_cpu_baseline:
-            threads = os.cpu_count() or 1
+            try:
+                threads = len(os.sched_getaffinity(0))
+            except AttributeError:
+                threads = os.cpu_count() or 1
+            threads = max(1, min(threads, 16))  # the one-GPU box's CPU share
             res["cpu_baseline"] = cpu_baseline(a.model, threads)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libctunet_hip.so")
-SOURCES = ["igemm.hip", "norm_elementwise.hip", "attention.hip", "loss_optim.hip"]
+SOURCES = ["igemm.hip", "conv3_halo.hip", "norm_elementwise.hip", "attention.hip", "loss_optim.hip", "mma.h"]
 
 CTU_F32, CTU_BF16 = 0, 1
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -42,11 +42,14 @@ class AttnGeom(C.Structure):
 _SIGS = {
     "ctu_igemm_nt": [_i32, _vp, _vp, _vp, _vp, C.POINTER(Geom), C.POINTER(Epilogue), _vp],
     "ctu_igemm_tn": [_i32, _vp, _i32, _vp, _vp, _vp, C.POINTER(Geom), _vp],
+    "ctu_conv3_halo": [_i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 10 + [_vp],
+    "ctu_conv3_halo_wgrad": [_i32, _vp, _vp, _vp, _vp] + [_i32] * 7 + [_vp],
+    "ctu_pack_frag": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp],
     "ctu_conv_cin1_fwd": [_i32, _vp, _vp, _vp, C.POINTER(Geom), _vp],
     "ctu_conv_cin1_wgrad": [_i32, _vp, _vp, _vp, C.POINTER(Geom), _vp],
     "ctu_permute3": [_vp, _vp, _i32] + [_i64] * 9 + [_i32, _vp],
     "ctu_colsum": [_i32, _vp, _i64, _i32, _i32, _vp, _vp],
-    "ctu_in_stats": [_i32, _vp, _i32, _i64, _i32, _vp, _vp],
+    "ctu_in_stats": [_i32, _vp, _i32, _i64, _i32, _vp, _vp, _vp],
     "ctu_in_apply": [_i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp],
     "ctu_in_bwd_reduce": [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp],
     "ctu_in_bwd_apply": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp],

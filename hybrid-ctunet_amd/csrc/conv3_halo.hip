@@ -1,0 +1,367 @@
+// 3x3x3, stride 1, padding 1 convolution (forward and data gradient) with an LDS-resident halo brick.
+//
+// The generic implicit GEMM (igemm.hip) re-gathers every input voxel once per tap through L2 and pays a workgroup
+// barrier every 4 MFMAs per wave.  Here a workgroup owns a 4 x 8 x 8 brick of output voxels: for each 32-channel
+// chunk it stages the 6 x 10 x 10 input halo in LDS ONCE and all 27 taps read their A fragments from it at a
+// constant address offset; the B fragments (weights) are streamed global -> registers in MFMA-fragment order
+// (1 KiB contiguous per wave-instruction, L2-resident panel), so there is no barrier inside a chunk at all.
+//
+// Replaces nn.Conv3d(k=3, s=1, p=1, bias=False) and its input gradient: ResBlock.conv1/conv2
+// (networks/hybrid_CTUNet.py:57-74) and Bottleneck.conv2 (networks/resnet.py:98) - 80 % of the model's FLOPs
+// (SURVEY.md section 2.2 row K1).  Input may be the channel concat of two tensors (torch.cat, hybrid_CTUNet.py:199,618);
+// the data gradient then splits its output columns over two destinations.
+#include "mma.h"
+
+#define HB_D 4
+#define HB_H 8
+#define HB_W 8
+#define HALO_D (HB_D + 2)
+#define HALO_H (HB_H + 2)
+#define HALO_W (HB_W + 2)
+#define HALO_VOX (HALO_D * HALO_H * HALO_W)  // 600
+
+struct HaloArgs {
+  const void* x1;
+  const void* x2;
+  const void* wfrag;  // [K/32][27][2][Npad/32][64 lanes][8]  (ctu_pack_frag)
+  void* out;
+  void* out2;
+  int B, D, H, W, C1, C2, N, n_split, ldc, ldc2;
+  int nbd, nbh, nbw, ntn;  // brick grid, 32-wide n tiles in the whole panel
+};
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void conv3_halo_kernel(const HaloArgs p) {
+  constexpr int EV = 16 / sizeof(T);
+  constexpr int CK = 32;              // channels per chunk
+  constexpr int LDT = CK + EV;        // padded voxel row in LDS (80 B bf16 / 144 B f32)
+  constexpr int VPV = CK / EV;        // 16-byte vectors per voxel per chunk
+  constexpr int FRAG = 64 * 8;        // elements of one packed fragment tile (64 lanes x 8)
+  constexpr int STAGE_LD = 32 + 4;
+  constexpr size_t LDS_HALO = (size_t)HALO_VOX * LDT * sizeof(T);
+  constexpr size_t LDS_EPI = 4 * 32 * (size_t)STAGE_LD * sizeof(float);
+  constexpr size_t LDS_BYTES = LDS_HALO > LDS_EPI ? LDS_HALO : LDS_EPI;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  T* halo = reinterpret_cast<T*>(smem);
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  // brick coordinates (blockIdx.x) and n block (blockIdx.y)
+  int t = blockIdx.x;
+  const int bw = t % p.nbw; t /= p.nbw;
+  const int bh = t % p.nbh; t /= p.nbh;
+  const int bd = t % p.nbd;
+  const int b = t / p.nbd;
+  const int d0 = bd * HB_D, h0 = bh * HB_H, w0 = bw * HB_W;
+  const int nt0 = blockIdx.y * NT;  // first 32-wide n tile of this block
+  const int K = p.C1 + p.C2;
+  const int nchunks = K / CK;
+  const T* x1 = reinterpret_cast<const T*>(p.x1);
+  const T* x2 = reinterpret_cast<const T*>(p.x2);
+  const T* wf = reinterpret_cast<const T*>(p.wfrag);
+
+  // A-fragment base addresses (elements) of this lane for its two 32-voxel row tiles: wave = d slice,
+  // local voxel v = 32 i + r -> (hh, ww) = (v >> 3, v & 7); tap (0,0,0) reads halo voxel (wave, hh, ww)
+  int abase[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int v = 32 * i + r;
+    abase[i] = ((wave * HALO_H + (v >> 3)) * HALO_W + (v & 7)) * LDT + h * 8;
+  }
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int c0 = ch * CK;
+    const T* src = (c0 < p.C1) ? x1 : x2;
+    const int cs = (c0 < p.C1) ? p.C1 : p.C2;
+    const int cc = (c0 < p.C1) ? c0 : c0 - p.C1;
+    __syncthreads();  // every wave is done reading the previous chunk's halo
+    for (int v = tid; v < HALO_VOX * VPV; v += 256) {
+      const int vox = v / VPV, part = v - vox * VPV;
+      const int hw = vox % HALO_W;
+      const int tq = vox / HALO_W;
+      const int hh = tq % HALO_H, hd = tq / HALO_H;
+      const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+      u32x4 val = {0u, 0u, 0u, 0u};
+      if ((unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W)
+        val = *reinterpret_cast<const u32x4*>(src + ((((size_t)b * p.D + gd) * p.H + gh) * p.W + gw) * cs + cc + part * EV);
+      *reinterpret_cast<u32x4*>(&halo[vox * LDT + part * EV]) = val;
+    }
+    __syncthreads();
+
+    // 54 k-steps (27 taps x 2 halves of the chunk); B fragments stream from the packed panel, prefetched one step
+    // ahead in registers
+    const T* wch = wf + ((size_t)ch * 54 * p.ntn + nt0) * FRAG + lane * 8;
+    // two named register sets (static indexing: a runtime-indexed fragment array would go to scratch)
+    typename Mma<T>::Frag fb0[NT], fb1[NT];
+    auto load_b = [&](int ks, typename Mma<T>::Frag (&f)[NT]) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) f[j] = Mma<T>::load(wch + ((size_t)ks * p.ntn + j) * FRAG);
+    };
+    auto step = [&](int tap, int kk, const typename Mma<T>::Frag (&f)[NT]) {
+      const int tw = tap % 3, tq = tap / 3;
+      const int th = tq % 3, td = tq / 3;
+      const int aoff = ((td * HALO_H + th) * HALO_W + tw) * LDT + kk * 16;
+      typename Mma<T>::Frag fa[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = Mma<T>::load(&halo[abase[i] + aoff]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) Mma<T>::mma(fa[i], f[j], acc[i][j]);
+    };
+    load_b(0, fb0);
+    for (int tap = 0; tap < 27; ++tap) {
+      load_b(2 * tap + 1, fb1);
+      step(tap, 0, fb0);
+      if (tap + 1 < 27) load_b(2 * tap + 2, fb0);
+      step(tap, 1, fb1);
+    }
+  }
+
+  // ---- epilogue: per (row tile, n tile): accumulators -> wave-private LDS tile -> 8-wide vectors -> global ----
+  __syncthreads();
+  float* stage = reinterpret_cast<float*>(smem) + wave * 32 * STAGE_LD;
+  T* out = reinterpret_cast<T*>(p.out);
+  T* out2 = reinterpret_cast<T*>(p.out2);
+  const int gd = d0 + wave;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) stage[((e & 3) + 8 * (e >> 2) + 4 * h) * STAGE_LD + r] = acc[i][j][e];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int vv = lane + 64 * q;       // 128 vectors: 32 rows x 4 groups of 8 channels
+        const int row = vv >> 2, cv = vv & 3;
+        const int v = 32 * i + row;
+        const int gh = h0 + (v >> 3), gw = w0 + (v & 7);
+        const int n = (nt0 + j) * 32 + cv * 8;
+        if (gd < p.D && gh < p.H && gw < p.W && n < p.N) {
+          float xv[8];
+          load8(&stage[row * STAGE_LD + cv * 8], xv);
+          const size_t m = (((size_t)b * p.D + gd) * p.H + gh) * p.W + gw;
+          if (p.n_split > 0 && n >= p.n_split) store8(out2 + m * p.ldc2 + (n - p.n_split), xv);
+          else store8(out + m * p.ldc + n, xv);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename T>
+static int launch_halo(const HaloArgs& p, hipStream_t s) {
+  const int ntn = p.ntn;
+  const int bricks = p.B * p.nbd * p.nbh * p.nbw;
+  if (ntn >= 4 && ntn % 4 == 0)
+    hipLaunchKernelGGL((conv3_halo_kernel<T, 4>), dim3(bricks, ntn / 4), dim3(256), 0, s, p);
+  else if (ntn % 2 == 0)
+    hipLaunchKernelGGL((conv3_halo_kernel<T, 2>), dim3(bricks, ntn / 2), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((conv3_halo_kernel<T, 1>), dim3(bricks, ntn), dim3(256), 0, s, p);
+  return ctu_check_launch("conv3_halo");
+}
+
+extern "C" int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, const void* wfrag, void* out, void* out2,
+                              int32_t B, int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N,
+                              int32_t n_split, int32_t ldc, int32_t ldc2, ctu_stream_t stream) {
+  CTU_REQUIRE(x1 && wfrag && out, "conv3_halo: null pointer");
+  CTU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3_halo: bad dims");
+  CTU_REQUIRE(C1 > 0 && C1 % 32 == 0 && C2 >= 0 && C2 % 32 == 0 && (C2 == 0 || x2), "conv3_halo: C1, C2 must be multiples of 32");
+  CTU_REQUIRE(N > 0 && N % 8 == 0 && ldc % 8 == 0 && ldc > 0, "conv3_halo: N, ldc must be multiples of 8");
+  CTU_REQUIRE(n_split % 32 == 0 && (n_split == 0 || (out2 && ldc2 > 0 && ldc2 % 8 == 0)), "conv3_halo: bad split");
+  HaloArgs p;
+  p.x1 = x1; p.x2 = x2; p.wfrag = wfrag; p.out = out; p.out2 = out2;
+  p.B = B; p.D = D; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.N = N; p.n_split = n_split; p.ldc = ldc; p.ldc2 = ldc2;
+  p.nbd = (D + HB_D - 1) / HB_D; p.nbh = (H + HB_H - 1) / HB_H; p.nbw = (W + HB_W - 1) / HB_W;
+  p.ntn = (N + 31) / 32;
+  CTU_REQUIRE((int64_t)B * p.nbd * p.nbh * p.nbw < (1ll << 31), "conv3_halo: too many bricks");
+  CTU_DISPATCH(dtype, return launch_halo<float>(p, (hipStream_t)stream), return launch_halo<bf16>(p, (hipStream_t)stream));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient of the same convolution:  dw[tap][n][c] += sum_v dY[v][n] * X[v + tap - 1][c].
+// A workgroup owns one (32 output channels) x (32 input channels) tile for ALL 27 taps and walks a range of bricks
+// with the accumulators resident: wave w holds taps w, w+4, ... (7 or 6 tiles of 32x32).  Per brick the X halo chunk
+// and the dY tile are staged in LDS once; the K dimension of the MFMA is the voxel index, so both operands are
+// read "transposed" (8 voxels of one channel per lane).  Finally each wave adds its tiles into the fp32 panel.
+// ---------------------------------------------------------------------------------------------------------
+struct HaloWgArgs {
+  const void* dy;
+  const void* x1;
+  const void* x2;
+  float* dw;  // [27][N][K]
+  int B, D, H, W, C1, C2, N;
+  int nbd, nbh, nbw, nbricks, bricks_per_block, tiles_c;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv3_halo_wgrad_kernel(const HaloWgArgs p) {
+  constexpr int EV = 16 / sizeof(T);
+  constexpr int CK = 32;
+  constexpr int LDT = CK + EV;   // halo voxel row (elements)
+  constexpr int LDY = 32 + EV;   // dY tile row
+  constexpr int VPV = CK / EV;
+  constexpr int BRICK = HB_D * HB_H * HB_W;  // 256
+  __shared__ __attribute__((aligned(16))) T halo[HALO_VOX * LDT];
+  __shared__ __attribute__((aligned(16))) T dyt[BRICK * LDY];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int n0 = (blockIdx.x / p.tiles_c) * 32;
+  const int c0 = (blockIdx.x % p.tiles_c) * CK;
+  const int K = p.C1 + p.C2;
+  const T* src = (c0 < p.C1) ? reinterpret_cast<const T*>(p.x1) : reinterpret_cast<const T*>(p.x2);
+  const int cs = (c0 < p.C1) ? p.C1 : p.C2;
+  const int cc = (c0 < p.C1) ? c0 : c0 - p.C1;
+  const T* dy = reinterpret_cast<const T*>(p.dy);
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  const int brick_begin = blockIdx.y * p.bricks_per_block;
+  const int brick_end = min(p.nbricks, brick_begin + p.bricks_per_block);
+  for (int brick = brick_begin; brick < brick_end; ++brick) {
+    int t = brick;
+    const int bw = t % p.nbw; t /= p.nbw;
+    const int bh = t % p.nbh; t /= p.nbh;
+    const int bd = t % p.nbd;
+    const int b = t / p.nbd;
+    const int d0 = bd * HB_D, h0 = bh * HB_H, w0 = bw * HB_W;
+    __syncthreads();
+    for (int v = tid; v < HALO_VOX * VPV; v += 256) {
+      const int vox = v / VPV, part = v - vox * VPV;
+      const int hw = vox % HALO_W;
+      const int tq = vox / HALO_W;
+      const int hh = tq % HALO_H, hd = tq / HALO_H;
+      const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+      u32x4 val = {0u, 0u, 0u, 0u};
+      if ((unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W)
+        val = *reinterpret_cast<const u32x4*>(src + ((((size_t)b * p.D + gd) * p.H + gh) * p.W + gw) * cs + cc + part * EV);
+      *reinterpret_cast<u32x4*>(&halo[vox * LDT + part * EV]) = val;
+    }
+    for (int v = tid; v < BRICK * VPV; v += 256) {
+      const int vox = v / VPV, part = v - vox * VPV;
+      const int gd = d0 + (vox >> 6), gh = h0 + ((vox >> 3) & 7), gw = w0 + (vox & 7);
+      const int n = n0 + part * EV;
+      u32x4 val = {0u, 0u, 0u, 0u};
+      if (gd < p.D && gh < p.H && gw < p.W && n < p.N)
+        val = *reinterpret_cast<const u32x4*>(dy + ((((size_t)b * p.D + gd) * p.H + gh) * p.W + gw) * p.N + n);
+      *reinterpret_cast<u32x4*>(&dyt[vox * LDY + part * EV]) = val;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 0; s < 16; ++s) {
+      const int d = s >> 2, hh = 2 * (s & 3) + h;  // this lane half's row of 8 voxels along w
+      const typename Mma<T>::Frag fa = Mma<T>::gather(&dyt[(d * 64 + hh * 8) * LDY + r], LDY);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int tap = wave + 4 * i;
+        if (tap < 27) {  // wave-uniform
+          const int tw = tap % 3, tq = tap / 3;
+          const int th = tq % 3, td = tq / 3;
+          const typename Mma<T>::Frag fb =
+              Mma<T>::gather(&halo[(((d + td) * HALO_H + hh + th) * HALO_W + tw) * LDT + r], LDT);
+          Mma<T>::mma(fa, fb, acc[i]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = wave + 4 * i;
+    if (tap < 27) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int c = c0 + r;
+        if (n < p.N && c < K) atomicAdd(&p.dw[((size_t)tap * p.N + n) * K + c], acc[i][e]);
+      }
+    }
+  }
+}
+
+extern "C" int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void* x1, const void* x2, float* dw, int32_t B,
+                                    int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N,
+                                    ctu_stream_t stream) {
+  CTU_REQUIRE(dy && x1 && dw, "conv3_halo_wgrad: null pointer");
+  CTU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3_halo_wgrad: bad dims");
+  CTU_REQUIRE(C1 > 0 && C1 % 32 == 0 && C2 >= 0 && C2 % 32 == 0 && (C2 == 0 || x2), "conv3_halo_wgrad: C1, C2 %% 32");
+  CTU_REQUIRE(N > 0 && N % 8 == 0, "conv3_halo_wgrad: N %% 8");
+  HaloWgArgs p;
+  p.dy = dy; p.x1 = x1; p.x2 = x2; p.dw = dw;
+  p.B = B; p.D = D; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.N = N;
+  p.nbd = (D + HB_D - 1) / HB_D; p.nbh = (H + HB_H - 1) / HB_H; p.nbw = (W + HB_W - 1) / HB_W;
+  const int64_t nbricks = (int64_t)B * p.nbd * p.nbh * p.nbw;
+  CTU_REQUIRE(nbricks < (1ll << 31), "conv3_halo_wgrad: too many bricks");
+  p.nbricks = (int)nbricks;
+  p.tiles_c = (C1 + C2) / 32;
+  const int tiles = ((N + 31) / 32) * p.tiles_c;
+  int splits = (512 + tiles - 1) / tiles;  // ~2 resident workgroups per CU
+  if (splits > p.nbricks) splits = p.nbricks;
+  if (splits < 1) splits = 1;
+  p.bricks_per_block = (p.nbricks + splits - 1) / splits;
+  splits = (p.nbricks + p.bricks_per_block - 1) / p.bricks_per_block;
+  CTU_REQUIRE(splits <= 65535, "conv3_halo_wgrad: too many splits");
+  dim3 grid(tiles, splits);
+  hipStream_t s = (hipStream_t)stream;
+  CTU_DISPATCH(dtype, hipLaunchKernelGGL(conv3_halo_wgrad_kernel<float>, grid, dim3(256), 0, s, p),
+               hipLaunchKernelGGL(conv3_halo_wgrad_kernel<bf16>, grid, dim3(256), 0, s, p));
+  return ctu_check_launch("conv3_halo_wgrad");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fragment-order weight packing.  dst[((chunk*taps + tap)*2 + kk)*ntn + nt][lane][j] = W(n, c, tap_src) with
+// n = nt*32 + (lane & 31), c = chunk*32 + kk*16 + 8*(lane >> 5) + j, tap_src = flip ? taps-1-tap : tap,
+// W(n, c, t) = src[n*sn + c*sc + t*st]; zero for n >= N or c >= K.
+// ---------------------------------------------------------------------------------------------------------
+template <typename TD>
+__global__ __launch_bounds__(256) void pack_frag_kernel(const float* __restrict__ src, TD* __restrict__ dst, const int N,
+                                                        const int K, const int taps, const int64_t sn, const int64_t sc,
+                                                        const int64_t st, const int flip, const int ntn,
+                                                        const int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int j = (int)(i & 7);
+    const int lane = (int)((i >> 3) & 63);
+    int64_t q = i >> 9;
+    const int nt = (int)(q % ntn); q /= ntn;
+    const int kk = (int)(q & 1); q >>= 1;
+    const int tap = (int)(q % taps);
+    const int chunk = (int)(q / taps);
+    const int n = nt * 32 + (lane & 31);
+    const int c = chunk * 32 + kk * 16 + 8 * (lane >> 5) + j;
+    const int ts = flip ? taps - 1 - tap : tap;
+    float v = 0.f;
+    if (n < N && c < K) v = src[(int64_t)n * sn + (int64_t)c * sc + (int64_t)ts * st];
+    dst[i] = (TD)v;
+  }
+}
+
+extern "C" int ctu_pack_frag(const float* src, void* dst, ctu_dtype dst_dtype, int32_t N, int32_t K, int32_t taps,
+                             int64_t sn, int64_t sc, int64_t st, int32_t flip, ctu_stream_t stream) {
+  CTU_REQUIRE(src && dst && N > 0 && K > 0 && K % 32 == 0 && taps > 0, "pack_frag: bad args (K %% 32)");
+  const int ntn = (N + 31) / 32;
+  const int64_t total = (int64_t)(K / 32) * taps * 2 * ntn * 512;
+  const unsigned grid = grid_for(total, 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dst_dtype == CTU_F32)
+    hipLaunchKernelGGL(pack_frag_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, N, K, taps, sn, sc, st, flip,
+                       ntn, total);
+  else if (dst_dtype == CTU_BF16)
+    hipLaunchKernelGGL(pack_frag_kernel<bf16>, dim3(grid), dim3(256), 0, s, src, (bf16*)dst, N, K, taps, sn, sc, st, flip,
+                       ntn, total);
+  else { ctu_set_error("pack_frag: bad dtype"); return CTU_ERR_ARG; }
+  return ctu_check_launch("pack_frag");
+}

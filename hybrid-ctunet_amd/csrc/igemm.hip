@@ -11,66 +11,7 @@
 // and nn.Linear (networks/vit.py:36-62,117; networks/hybrid_CTUNet.py:402-679), forward and backward.
 #include "common.h"
 
-// ---------------------------------------------------------------------------------------------------------
-// MFMA wrappers.  Fragment = 8 consecutive-k elements of one row (lane r = row, lane half h -> k = 8h..8h+7)
-// ---------------------------------------------------------------------------------------------------------
-template <typename T> struct Mma;
-
-template <> struct Mma<bf16> {
-  typedef bf16x8 Frag;
-  static __device__ __forceinline__ Frag load(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
-  // k-strided gather (transposed operand): element j at p[j*stride]
-  static __device__ __forceinline__ Frag gather(const bf16* p, int stride) {
-    Frag f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = p[j * stride];
-    return f;
-  }
-  static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
-
-template <> struct Mma<float> {
-  struct Frag { float v[8]; };
-  static __device__ __forceinline__ Frag load(const float* p) {
-    Frag f;
-    const f32x4 lo = *reinterpret_cast<const f32x4*>(p);
-    const f32x4 hi = *reinterpret_cast<const f32x4*>(p + 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { f.v[j] = lo[j]; f.v[4 + j] = hi[j]; }
-    return f;
-  }
-  static __device__ __forceinline__ Frag gather(const float* p, int stride) {
-    Frag f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f.v[j] = p[j * stride];
-    return f;
-  }
-  // 32x32x2: lane (r,h) supplies A[r][k=h], B[k=h][r]; step j pairs k = j (h=0) with k = 8+j (h=1) on both operands
-  static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], c, 0, 0, 0);
-  }
-};
-
-__device__ __forceinline__ bool gather_coord(int o, int t, int s, int p, int n_in, int mode, int& i) {
-  if (mode == 0) {
-    i = o * s - p + t;
-    return (unsigned)i < (unsigned)n_in;
-  }
-  const int z = o + p - t;  // stride is 1 or 2 in mode 1 (checked on the host)
-  if (z < 0) return false;
-  i = (s == 1) ? z : (z >> 1);
-  return ((s == 1) || !(z & 1)) && i < n_in;
-}
-
-// XCD-aware bijective remap of a 1-D block id: blocks dealt round-robin to 8 XCDs get contiguous tile ranges,
-// so neighbouring tiles (which share halo voxels / weight panels) hit the same L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  const int q = nwg >> 3, rr = nwg & 7, x = bid & 7;
-  return (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + (bid >> 3);
-}
+#include "mma.h"
 
 struct NtArgs {
   const void* a1;
@@ -301,7 +242,7 @@ static int check_geom(const ctu_geom* g) {
   CTU_REQUIRE(g->B > 0 && g->Di > 0 && g->Hi > 0 && g->Wi > 0 && g->Do > 0 && g->Ho > 0 && g->Wo > 0, "bad dims");
   CTU_REQUIRE(g->C1 > 0 && g->C1 % 8 == 0 && g->C2 >= 0 && g->C2 % 8 == 0, "C1/C2 must be multiples of 8 (%d,%d)",
               g->C1, g->C2);
-  CTU_REQUIRE(g->C2 == 0 || g->C1 % 32 == 0, "concatenated source needs C1 %% 32 == 0 (C1=%d)", g->C1);
+  // (a 16-byte vector never straddles the two sources because C1 % 8 == 0)
   CTU_REQUIRE(g->N > 0 && g->N % 8 == 0, "N must be a multiple of 8 (%d)", g->N);
   CTU_REQUIRE(g->kd > 0 && g->kh > 0 && g->kw > 0 && g->sd > 0 && g->sh > 0 && g->sw > 0, "bad kernel/stride");
   CTU_REQUIRE(g->mode == 0 || g->mode == 1, "bad mode %d", g->mode);

@@ -8,9 +8,9 @@
 // =========================================================================================================
 // stats[b][c] = (sum, sumsq).  grid (chunks, B); block 256 = (C/8 column groups) x (256/(C/8) row lanes)
 template <typename T>
-__global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ x, float* __restrict__ stats,
+__global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ x, double* __restrict__ stats,
                                                        const int64_t S, const int C, const int64_t rows_per_block) {
-  __shared__ float red[256 * 16];
+  __shared__ double red[256 * 16];
   const int ncg = C >> 3;                 // column groups (<= 256, checked on host)
   const int tid = threadIdx.x;
   const int cg = tid % ncg, rl = tid / ncg;
@@ -18,16 +18,22 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ x, 
   const int b = blockIdx.y;
   const int64_t s_begin = (int64_t)blockIdx.x * rows_per_block;
   const int64_t s_end = min(S, s_begin + rows_per_block);
-  float s1[8], s2[8];
+  // Shifted sums: accumulate (x - K), (x - K)^2 with K = the channel's first voxel.  Conv outputs fed by
+  // post-activation tensors can have |mean| >> std; E[x^2] - E[x]^2 would then cancel catastrophically in fp32.
+  // fp64 accumulators: this net amplifies rounding noise in the statistics ~1000x (DESIGN.md "Numerics"); the kernel
+  // is HBM-bound, so the wider adds are free.
+  double s1[8], s2[8];
+  float shift[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.0; s2[e] = 0.0; shift[e] = 0.f; }
   if (rl < rlanes) {
     const T* base = x + ((size_t)b * S) * C + cg * 8;
+    load8(base, shift);
     for (int64_t s = s_begin + rl; s < s_end; s += rlanes) {
       float v[8];
       load8(base + (size_t)s * C, v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
+      for (int e = 0; e < 8; ++e) { const double d = (double)(v[e] - shift[e]); s1[e] += d; s2[e] += d * d; }
     }
   }
 #pragma unroll
@@ -37,21 +43,34 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ x, 
   for (int o = tid; o < C * 2; o += 256) {
     const int c = o >> 1, which = o & 1;
     const int g = c >> 3, e = c & 7;
-    float acc = 0.f;
+    double acc = 0.0;
     for (int r = 0; r < rlanes; ++r) acc += red[(r * ncg + g) * 16 + which * 8 + e];
     atomicAdd(&stats[((size_t)b * C + c) * 2 + which], acc);
   }
 }
 
-__device__ __forceinline__ void in_mean_rstd(const float* stats, int b, int C, int c0, float inv_s, float (&mean)[8],
+// (sum(x-K), sum(x-K)^2) in fp64 -> (mean, rstd) in fp32
+template <typename T>
+__global__ __launch_bounds__(256) void in_finalize_kernel(const T* __restrict__ x, const double* __restrict__ acc,
+                                                          float* __restrict__ stats, const int B, const int64_t S,
+                                                          const int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  const double inv_s = 1.0 / (double)S;
+  const double k = (double)(float)x[((size_t)b * S) * C + c];
+  const double m = acc[(size_t)i * 2] * inv_s;
+  const double var = fmax(acc[(size_t)i * 2 + 1] * inv_s - m * m, 0.0);
+  stats[(size_t)i * 2] = (float)(k + m);
+  stats[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)NORM_EPS));
+}
+
+__device__ __forceinline__ void in_mean_rstd(const float* stats, int b, int C, int c0, float /*inv_s*/, float (&mean)[8],
                                              float (&rstd)[8]) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const float s1 = stats[((size_t)b * C + c0 + e) * 2], s2 = stats[((size_t)b * C + c0 + e) * 2 + 1];
-    const float mu = s1 * inv_s;
-    const float var = fmaxf(s2 * inv_s - mu * mu, 0.f);
-    mean[e] = mu;
-    rstd[e] = rsqrtf(var + NORM_EPS);
+    mean[e] = stats[((size_t)b * C + c0 + e) * 2];
+    rstd[e] = stats[((size_t)b * C + c0 + e) * 2 + 1];
   }
 }
 
@@ -89,9 +108,9 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, 
 template <typename T>
 __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const T* __restrict__ y, const float* __restrict__ stats,
-                                                            float* __restrict__ sums, const int64_t S, const int C,
+                                                            double* __restrict__ sums, const int64_t S, const int C,
                                                             const int act, const int64_t rows_per_block) {
-  __shared__ float red[256 * 16];
+  __shared__ double red[256 * 16];
   const int ncg = C >> 3;
   const int tid = threadIdx.x;
   const int cg = tid % ncg, rl = tid / ncg;
@@ -99,9 +118,9 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
   const int b = blockIdx.y;
   const int64_t s_begin = (int64_t)blockIdx.x * rows_per_block;
   const int64_t s_end = min(S, s_begin + rows_per_block);
-  float s1[8], s2[8];
+  double s1[8], s2[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.0; s2[e] = 0.0; }
   if (rl < rlanes) {
     float mean[8], rstd[8];
     in_mean_rstd(stats, b, C, cg * 8, 1.0f / (float)S, mean, rstd);
@@ -119,8 +138,8 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        s1[e] += g[e];
-        s2[e] = fmaf(g[e], (xv[e] - mean[e]) * rstd[e], s2[e]);
+        s1[e] += (double)g[e];
+        s2[e] += (double)g[e] * (double)((xv[e] - mean[e]) * rstd[e]);
       }
     }
   }
@@ -130,7 +149,7 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
   for (int o = tid; o < C * 2; o += 256) {
     const int c = o >> 1, which = o & 1;
     const int g = c >> 3, e = c & 7;
-    float acc = 0.f;
+    double acc = 0.0;
     for (int r = 0; r < rlanes; ++r) acc += red[(r * ncg + g) * 16 + which * 8 + e];
     atomicAdd(&sums[((size_t)b * C + c) * 2 + which], acc);
   }
@@ -139,7 +158,7 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const T* __restrict__ y, const float* __restrict__ stats,
-                                                           const float* __restrict__ sums, T* __restrict__ dx,
+                                                           const double* __restrict__ sums, T* __restrict__ dx,
                                                            T* __restrict__ dres, const int B, const int64_t S,
                                                            const int C, const int act) {
   const int ncg = C >> 3;
@@ -162,8 +181,8 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float m1 = sums[((size_t)b * C + cg * 8 + e) * 2] * inv_s;
-      const float m2 = sums[((size_t)b * C + cg * 8 + e) * 2 + 1] * inv_s;
+      const float m1 = (float)(sums[((size_t)b * C + cg * 8 + e) * 2] / (double)S);
+      const float m2 = (float)(sums[((size_t)b * C + cg * 8 + e) * 2 + 1] / (double)S);
       const float xh = (xv[e] - mean[e]) * rstd[e];
       o[e] = rstd[e] * (g[e] - m1 - xh * m2);
     }
@@ -186,15 +205,23 @@ static int64_t in_rows_per_block(int64_t S, int B) {
   return rows;
 }
 
-extern "C" int ctu_in_stats(ctu_dtype dtype, const void* x, int32_t B, int64_t S, int32_t C, float* stats,
+extern "C" int ctu_in_stats(ctu_dtype dtype, const void* x, int32_t B, int64_t S, int32_t C, double* acc, float* stats,
                             ctu_stream_t stream) {
   if (int rc = check_in(x, B, S, C)) return rc;
-  CTU_REQUIRE(stats, "null stats");
+  CTU_REQUIRE(stats && acc, "null stats/acc");
   const int64_t rows = in_rows_per_block(S, B);
   dim3 grid((unsigned)((S + rows - 1) / rows), B);
   hipStream_t s = (hipStream_t)stream;
-  CTU_DISPATCH(dtype, hipLaunchKernelGGL(in_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)x, stats, S, C, rows),
-               hipLaunchKernelGGL(in_stats_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, stats, S, C, rows));
+  const dim3 fgrid((B * C + 255) / 256);
+  CTU_DISPATCH(dtype,
+               {
+                 hipLaunchKernelGGL(in_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)x, acc, S, C, rows);
+                 hipLaunchKernelGGL(in_finalize_kernel<float>, fgrid, dim3(256), 0, s, (const float*)x, acc, stats, B, S, C);
+               },
+               {
+                 hipLaunchKernelGGL(in_stats_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, acc, S, C, rows);
+                 hipLaunchKernelGGL(in_finalize_kernel<bf16>, fgrid, dim3(256), 0, s, (const bf16*)x, acc, stats, B, S, C);
+               });
   return ctu_check_launch("in_stats");
 }
 
@@ -213,7 +240,7 @@ extern "C" int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, 
 }
 
 extern "C" int ctu_in_bwd_reduce(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
-                                 float* sums, int32_t B, int64_t S, int32_t C, int32_t act, ctu_stream_t stream) {
+                                 double* sums, int32_t B, int64_t S, int32_t C, int32_t act, ctu_stream_t stream) {
   if (int rc = check_in(x, B, S, C)) return rc;
   CTU_REQUIRE(dy && stats && sums && (y || !act), "null pointer");
   const int64_t rows = in_rows_per_block(S, B);
@@ -228,7 +255,7 @@ extern "C" int ctu_in_bwd_reduce(ctu_dtype dtype, const void* dy, const void* x,
 }
 
 extern "C" int ctu_in_bwd_apply(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
-                                const float* sums, void* dx, void* dres, int32_t B, int64_t S, int32_t C, int32_t act,
+                                const double* sums, void* dx, void* dres, int32_t B, int64_t S, int32_t C, int32_t act,
                                 ctu_stream_t stream) {
   if (int rc = check_in(x, B, S, C)) return rc;
   CTU_REQUIRE(dy && stats && sums && dx && (y || !act), "null pointer");

@@ -22,7 +22,7 @@ LRELU_SLOPE = 0.01
 # packed-weight cache
 # ---------------------------------------------------------------------------------------------------------------
 _weights_epoch = 0
-_pack_cache = weakref.WeakKeyDictionary()  # nn.Parameter -> {(kind, dtype): (version key, packed tensor)}
+_pack_cache = {}  # id(nn.Parameter) -> (weakref to it, {(kind, dtype): (version key, packed tensor)})
 
 
 def bump_weights_epoch():
@@ -38,10 +38,12 @@ def _packed(param: torch.Tensor, kind: str, dtype: torch.dtype, builder):
         with torch.no_grad():
             return builder()
     ver = (param._version, _weights_epoch, param.data_ptr(), tuple(param.shape))
-    slot = _pack_cache.get(param)
-    if slot is None:
-        slot = {}
-        _pack_cache[param] = slot
+    ent = _pack_cache.get(id(param))
+    if ent is None or ent[0]() is not param:
+        pid = id(param)
+        ent = (weakref.ref(param, lambda _r, pid=pid: _pack_cache.pop(pid, None)), {})
+        _pack_cache[pid] = ent
+    slot = ent[1]
     hit = slot.get((kind, dtype))
     if hit is not None and hit[0] == ver:
         return hit[1]
@@ -180,11 +182,16 @@ class ConvFn(torch.autograd.Function):
         K = C1 + C2
         assert weight.shape[1] == K
         dout = tuple((n + 2 * p - kk) // s + 1 for n, p, kk, s in zip((D, H, W), padding, k, stride))
-        wf = _packed(weight, "conv_f", x1.dtype,
-                     lambda: _pack(weight, (taps, N, K), (1, K * taps, taps), x1.dtype))
         out = torch.empty((B, *dout, N), dtype=x1.dtype, device=x1.device)
-        g = _geom(B, (D, H, W), dout, C1, C2, N, k, stride, padding, 0)
-        _igemm_nt(x1, x2, wf, out, g, _epi(N))
+        if _halo_ok(k, stride, padding) and C1 % 32 == 0 and C2 % 32 == 0:
+            wfr = _packed(weight, "conv_hf", x1.dtype, lambda: _pack_frag(weight, N, K, taps, K * taps, taps, 1, 0, x1.dtype))
+            call("ctu_conv3_halo", dcode(x1.dtype), ptr(x1), ptr(x2), ptr(wfr), ptr(out), None, B, D, H, W, C1, C2, N, 0,
+                 N, 0, stream())
+        else:
+            wf = _packed(weight, "conv_f", x1.dtype,
+                         lambda: _pack(weight, (taps, N, K), (1, K * taps, taps), x1.dtype))
+            g = _geom(B, (D, H, W), dout, C1, C2, N, k, stride, padding, 0)
+            _igemm_nt(x1, x2, wf, out, g, _epi(N))
         ctx.save_for_backward(x1, x2, weight)
         ctx.cfg = (stride, padding, k, dout)
         return out
@@ -200,23 +207,51 @@ class ConvFn(torch.autograd.Function):
         taps = k[0] * k[1] * k[2]
         g1 = g2 = gw = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
-            # dX[v][c] = sum_t sum_n dY[(v + p - t)/s][n] W[n][c][t]  ->  panel [t][c][n]
-            wd = _packed(weight, "conv_d", x1.dtype,
-                         lambda: _pack(weight, (taps, K, N), (1, taps, K * taps), x1.dtype))
             g1 = torch.empty_like(x1)
             g2 = torch.empty_like(x2) if x2 is not None else None
-            gd = _geom(B, dout, (D, H, W), N, 0, K, k, stride, padding, 1)
-            _igemm_nt(gy, None, wd, g1, gd, _epi(C1, out2=g2, n_split=C1 if x2 is not None else 0, ldc2=C2))
+            if _halo_ok(k, stride, padding) and N % 32 == 0 and (x2 is None or C1 % 32 == 0):
+                # dX = conv(dY, W flipped, in/out channels swapped): W'(n'=cin, c'=cout, t') = W[cout][cin][26 - t']
+                wfr = _packed(weight, "conv_hd", x1.dtype,
+                              lambda: _pack_frag(weight, K, N, taps, taps, K * taps, 1, 1, x1.dtype))
+                call("ctu_conv3_halo", dcode(x1.dtype), ptr(gy), None, ptr(wfr), ptr(g1), ptr(g2), B, D, H, W, N, 0, K,
+                     C1 if x2 is not None else 0, C1, C2, stream())
+            else:
+                # dX[v][c] = sum_t sum_n dY[(v + p - t)/s][n] W[n][c][t]  ->  panel [t][c][n]
+                wd = _packed(weight, "conv_d", x1.dtype,
+                             lambda: _pack(weight, (taps, K, N), (1, taps, K * taps), x1.dtype))
+                gd = _geom(B, dout, (D, H, W), N, 0, K, k, stride, padding, 1)
+                _igemm_nt(gy, None, wd, g1, gd, _epi(C1, out2=g2, n_split=C1 if x2 is not None else 0, ldc2=C2))
         if ctx.needs_input_grad[2]:
             panel = torch.zeros((taps, N, K), dtype=torch.float32, device=x1.device)
-            gq = _geom(B, (D, H, W), dout, C1, C2, N, k, stride, padding, 0)
-            _igemm_tn(gy, N, x1, x2, panel, gq)
+            if _halo_ok(k, stride, padding) and C1 % 32 == 0 and C2 % 32 == 0:
+                call("ctu_conv3_halo_wgrad", dcode(x1.dtype), ptr(gy), ptr(x1), ptr(x2), ptr(panel), B, D, H, W, C1, C2,
+                     N, stream())
+            else:
+                gq = _geom(B, (D, H, W), dout, C1, C2, N, k, stride, padding, 0)
+                _igemm_tn(gy, N, x1, x2, panel, gq)
             if taps == 1:
                 gw = panel.view(weight.shape)
             else:
                 gw = torch.empty(weight.shape, dtype=torch.float32, device=x1.device)
                 permute3(panel, gw, (N, K, taps), (K, 1, N * K), (K * taps, taps, 1))
         return g1, g2, gw, None, None
+
+
+USE_HALO_CONV = True  # tests flip this to run the generic implicit GEMM on the same shapes
+
+
+def _halo_ok(k, stride, padding) -> bool:
+    return USE_HALO_CONV and tuple(k) == (3, 3, 3) and tuple(stride) == (1, 1, 1) and tuple(padding) == (1, 1, 1)
+
+
+def _pack_frag(weight, N, K, taps, sn, sc, st, flip, dtype):
+    """MFMA-fragment-order panel [K/32][taps][2][ceil(N/32)][64][8] of W(n, c, t) = weight.flat[n*sn + c*sc + t*st]."""
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    out = torch.empty((K // 32) * taps * 2 * ((N + 31) // 32) * 512, dtype=dtype, device=w.device)
+    call("ctu_pack_frag", ptr(w), ptr(out), dcode(dtype), N, K, taps, sn, sc, st, flip, stream())
+    return out
 
 
 def _pack(weight, n, src_strides, dtype):
@@ -337,10 +372,11 @@ class InstanceNormFn(torch.autograd.Function):
         _check_act(x)
         B, C = x.shape[0], x.shape[-1]
         S = x.numel() // (B * C)
-        stats = torch.zeros((B, C, 2), dtype=torch.float32, device=x.device)
+        acc = torch.zeros((B, C, 2), dtype=torch.float64, device=x.device)
+        stats = torch.empty((B, C, 2), dtype=torch.float32, device=x.device)
         y = torch.empty_like(x)
         dc = dcode(x.dtype)
-        call("ctu_in_stats", dc, ptr(x), B, S, C, ptr(stats), stream())
+        call("ctu_in_stats", dc, ptr(x), B, S, C, ptr(acc), ptr(stats), stream())
         call("ctu_in_apply", dc, ptr(x), ptr(stats), ptr(residual), ptr(y), B, S, C, int(act), stream())
         ctx.save_for_backward(x, y, stats)
         ctx.act = int(act)
@@ -353,7 +389,7 @@ class InstanceNormFn(torch.autograd.Function):
         gy = gy.contiguous()
         B, C = x.shape[0], x.shape[-1]
         S = x.numel() // (B * C)
-        sums = torch.zeros((B, C, 2), dtype=torch.float32, device=x.device)
+        sums = torch.zeros((B, C, 2), dtype=torch.float64, device=x.device)
         gx = torch.empty_like(x)
         gres = torch.empty_like(x) if ctx.has_res else None
         dc = dcode(x.dtype)

@@ -92,6 +92,23 @@ int ctu_conv_cin1_fwd(ctu_dtype dtype, const void* x, const float* w, void* out,
 int ctu_conv_cin1_wgrad(ctu_dtype dtype, const void* x, const void* dy, float* dw, const ctu_geom* g,
                         ctu_stream_t stream);
 
+/* K1 fast path: 3x3x3 / stride 1 / padding 1 convolution with an LDS-resident halo brick (4x8x8 output voxels per
+ * workgroup, 27 taps served from one staged 6x10x10 halo per 32-channel chunk; weights streamed in MFMA-fragment
+ * order).  Forward of ResBlock.conv1/conv2 (hybrid_CTUNet.py:57-74) and Bottleneck.conv2 (resnet.py:98) when the
+ * stride is 1, and - with a flipped/transposed panel - their input gradient.  x1/x2: [B][D][H][W][C1|C2] (C multiples
+ * of 32); wfrag: panel from ctu_pack_frag; out: [rows][ldc]; columns >= n_split go to out2 (ldc2) when n_split > 0. */
+int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, const void* wfrag, void* out, void* out2,
+                   int32_t B, int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N, int32_t n_split,
+                   int32_t ldc, int32_t ldc2, ctu_stream_t stream);
+/* Weight gradient of the same convolution with the halo staged once per brick:
+ * dw[27][N][C1+C2] += sum_v dy[v][n] * x[v + tap - 1][c]  (fp32 atomics into a zeroed panel). dy: [B][D][H][W][N]. */
+int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void* x1, const void* x2, float* dw, int32_t B,
+                         int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N, ctu_stream_t stream);
+/* Pack fp32 weights W(n, c, tap) = src[n*sn + c*sc + tap*st] into MFMA-fragment order
+ * dst[K/32][taps][2][ceil(N/32)][64 lanes][8] (zero padded), optionally with the tap order reversed (flip = 1). */
+int ctu_pack_frag(const float* src, void* dst, ctu_dtype dst_dtype, int32_t N, int32_t K, int32_t taps, int64_t sn,
+                  int64_t sc, int64_t st, int32_t flip, ctu_stream_t stream);
+
 /* Strided 3-index permute + cast: dst[i0*d0 + i1*d1 + i2*d2] = (dst_dtype) src[i0*s0 + i1*s1 + i2*s2].
  * src is fp32 (master weights / packed fp32 gradients).  Used to pack weights into [taps][N][K] panels and
  * to unpack panel gradients back into the nn.Module's parameter layout (accumulate=1 adds into dst, fp32). */
@@ -103,18 +120,19 @@ int ctu_colsum(ctu_dtype dtype, const void* x, int64_t M, int32_t N, int32_t ld,
                ctu_stream_t stream);
 
 /* K6/K7 InstanceNorm3d (eps 1e-5, no affine) fused with residual add and LeakyReLU(0.01)
- * (resnet.py:97-124,156-157,198; hybrid_CTUNet.py:84-104).  x: [B][S][C]; stats: fp32 [B][C][2] = (sum, sumsq),
- * zeroed by the caller before ctu_in_stats.  y = act((x-mean)*rstd + residual). */
-int ctu_in_stats(ctu_dtype dtype, const void* x, int32_t B, int64_t S, int32_t C, float* stats,
+ * (resnet.py:97-124,156-157,198; hybrid_CTUNet.py:84-104).  x: [B][S][C]; acc_ws: fp64 [B][C][2] workspace zeroed
+ * by the caller; stats: fp32 [B][C][2] receives (mean, rstd).  Sums are shifted by the channel's first voxel and
+ * accumulated in fp64 (no E[x^2]-E[x]^2 cancellation; the deep IN stack amplifies statistic noise ~1000x).  y = act((x-mean)*rstd + residual). */
+int ctu_in_stats(ctu_dtype dtype, const void* x, int32_t B, int64_t S, int32_t C, double* acc_ws, float* stats,
                  ctu_stream_t stream);
 int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, const void* residual, void* y, int32_t B,
                  int64_t S, int32_t C, int32_t act, ctu_stream_t stream);
-/* backward: g = dy * act'(y); sums[b][c] = (sum g, sum g*xhat) (zeroed by caller);
+/* backward: g = dy * act'(y); sums[b][c] = (sum g, sum g*xhat), fp64, zeroed by caller;
  * dx = rstd*(g - s1/S - xhat*s2/S); dres = g when dres != NULL. */
 int ctu_in_bwd_reduce(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
-                      float* sums, int32_t B, int64_t S, int32_t C, int32_t act, ctu_stream_t stream);
+                      double* sums, int32_t B, int64_t S, int32_t C, int32_t act, ctu_stream_t stream);
 int ctu_in_bwd_apply(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
-                     const float* sums, void* dx, void* dres, int32_t B, int64_t S, int32_t C, int32_t act,
+                     const double* sums, void* dx, void* dres, int32_t B, int64_t S, int32_t C, int32_t act,
                      ctu_stream_t stream);
 
 /* K8 LayerNorm (eps 1e-5, affine) (vit.py:35,55,116,118; hybrid_CTUNet.py:456,518,630-631).

@@ -97,13 +97,21 @@ CONV_CASES = [  # B, D,H,W, C1, C2, N, k, s, p
     (2, 4, 5, 6, 64, 64, 32, 1, 1, 0),
     (1, 9, 10, 11, 16, 0, 24, 3, 1, 1),
     (1, 8, 8, 8, 32, 0, 32, 3, (2, 2, 1), 1),
+    (1, 4, 8, 8, 64, 0, 128, 3, 1, 1),    # halo kernel: NT=4, two channel chunks, exact brick
+    (2, 7, 9, 17, 32, 32, 64, 3, 1, 1),   # halo kernel: concat forward + split data gradient, ragged bricks
+    (1, 12, 12, 24, 96, 0, 32, 3, 1, 1),  # halo kernel: NT=1, three chunks
+    (1, 5, 16, 8, 64, 64, 160, 3, 1, 1),  # halo kernel: N=160 -> 5 n tiles (NT=1 path), concat
 ]
 
 
+@pytest.mark.parametrize("halo", [True, False])
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv3d(ops, dtype, case):
+def test_conv3d(ops, dtype, case, halo):
     B, D, H, W, C1, C2, N, k, s, p = case
+    if not halo and not (k == 3 and s == 1 and C1 % 32 == 0 and C2 % 32 == 0):
+        pytest.skip("generic kernel already exercised by the halo=True run of this case")
+    ops.USE_HALO_CONV = halo
     x1, x1h = dev(cl(rnd((B, C1, D, H, W), 1)), dtype, True)
     x2 = x2h = None
     if C2:
@@ -119,6 +127,7 @@ def test_conv3d(ops, dtype, case):
     close(y, cl(ref), dtype, "y")
     gy, gyh = dev(cl(rnd(tuple(ref.shape), 4)), dtype)
     y.backward(gy)
+    ops.USE_HALO_CONV = True
     ref.backward(cf(gyh))
     close(x1.grad, cl(xr1.grad), dtype, "gx1")
     if C2:
