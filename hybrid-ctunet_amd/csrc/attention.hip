@@ -7,37 +7,21 @@
 // (flash-style) with wavefront shuffle reductions; backward recomputes P from the saved log-sum-exp.
 // Tokens of a window are addressed arithmetically in the natural channels-last row order, so the reference's
 // Rearrange layers cost nothing.  These are < 1.5 % of the model's FLOPs; an MFMA version is listed in DESIGN.md.
-#include "common.h"
+#include "attn_common.h"
+
+#include <string.h>
+
+// test hook: "attn_valu" = 1 forces the VALU kernels below even where the MFMA kernels (attention_mfma.hip) apply
+static int g_attn_force_valu = 0;
+extern "C" int ctu_set_option(const char* name, int value) {
+  if (name && !strcmp(name, "attn_valu")) { g_attn_force_valu = value; return CTU_OK; }
+  ctu_set_error("unknown option %s", name ? name : "(null)");
+  return CTU_ERR_ARG;
+}
 
 #define ATT_KC 128   // rows per LDS chunk
 #define ATT_QPW 8    // queries (keys) per wave
 #define NEG_BIG (-1.0e30f)
-
-struct AttnCtx {
-  ctu_attn_geom g;
-  int ntok, nd, nh, nw, groups, relm, reloff, dim, ldq;
-};
-
-__device__ __forceinline__ int64_t attn_row(const AttnCtx& c, int grp, int i) {
-  if (c.g.part == 0) return (int64_t)grp * c.ntok + i;
-  int t = grp;
-  const int wz = t % c.nw; t /= c.nw;
-  const int wy = t % c.nh; t /= c.nh;
-  const int wx = t % c.nd;
-  const int b = t / c.nd;
-  const int win = c.g.win;
-  const int i3 = i % win, i2 = (i / win) % win, i1 = i / (win * win);
-  int d, h, w;
-  if (c.g.part == 1) { d = wx * win + i1; h = wy * win + i2; w = wz * win + i3; }
-  else { d = i1 * c.nd + wx; h = i2 * c.nh + wy; w = i3 * c.nw + wz; }
-  return (((int64_t)b * c.g.D + d) * c.g.H + h) * c.g.W + w;
-}
-// idx(i,j) = relcode(i) - relcode(j) + reloff  (hybrid_CTUNet.py:472-477)
-__device__ __forceinline__ int relcode(const AttnCtx& c, int i) {
-  const int win = c.g.win;
-  const int i3 = i % win, i2 = (i / win) % win, i1 = i / (win * win);
-  return (i1 * c.relm + i2) * c.relm + i3;
-}
 
 // load a chunk of rows [r0, r0+128) of one (group, head) column block at `col0` into LDS (fp32, stride DH+1)
 template <typename T, int DH>
@@ -399,6 +383,10 @@ extern "C" int ctu_attn_fwd(ctu_dtype dtype, const void* qkv, const float* bias_
   CTU_REQUIRE(!bias_table || g->part != 0, "bias table needs a window partition");
   dim3 grid(c.groups * g->heads, (c.ntok + 31) / 32);
   hipStream_t s = (hipStream_t)stream;
+  if (!g_attn_force_valu) {
+    const int rc = attn_mfma_fwd(dtype, qkv, bias_table, out, lse, c, s);
+    if (rc >= 0) return rc;
+  }
 #define ATT_FWD(T, DH) \
   hipLaunchKernelGGL((attn_fwd_kernel<T, DH>), grid, dim3(256), 0, s, (const T*)qkv, bias_table, (T*)out, lse, c)
   if (g->dh == 32) { CTU_DISPATCH(dtype, ATT_FWD(float, 32), ATT_FWD(bf16, 32)); }
@@ -417,6 +405,10 @@ extern "C" int ctu_attn_bwd(ctu_dtype dtype, const void* qkv, const float* bias_
   CTU_REQUIRE(!bias_table || g->part != 0, "bias table needs a window partition");
   dim3 grid(c.groups * g->heads, (c.ntok + 31) / 32);
   hipStream_t s = (hipStream_t)stream;
+  if (!g_attn_force_valu) {
+    const int rc = attn_mfma_bwd(dtype, qkv, bias_table, out, dout, lse, dqkv, dbias, c, s);
+    if (rc >= 0) return rc;
+  }
   const size_t tbl_bytes = dbias ? (size_t)c.relm * c.relm * c.relm * sizeof(float) : 0;
 #define ATT_BWD(T, DH)                                                                                               \
   do {                                                                                                               \

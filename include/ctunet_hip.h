@@ -36,6 +36,9 @@ typedef void* ctu_stream_t; /* hipStream_t */
 
 int ctu_abi_version(void);
 const char* ctu_last_error(void);
+/* Test hook (process-wide): "attn_valu" = 1 makes ctu_attn_fwd/_bwd use the VALU reference kernels even where the MFMA
+ * kernels apply, so both implementations can be checked against the oracle in one process. */
+int ctu_set_option(const char* name, int32_t value);
 
 /* Geometry of an implicit GEMM over a channels-last volume.
  * Row space  : M = B*Do*Ho*Wo rows (one per voxel of the Do x Ho x Wo grid).

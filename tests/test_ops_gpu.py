@@ -223,9 +223,16 @@ def _attn_ref(qkv, heads, scale, bias=None):
     return (torch.softmax(sim, -1) @ v).transpose(1, 2).reshape(G, n, dim)
 
 
+def _set_attn_impl(valu):
+    from hybrid_ctunet_amd import _lib
+    _lib.call("ctu_set_option", b"attn_valu", 1 if valu else 0)
+
+
+@pytest.mark.parametrize("valu", [False, True])
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("B,n,heads,dh", [(2, 50, 2, 32), (1, 432, 3, 64), (2, 130, 2, 64)])
-def test_attention_global(ops, dtype, B, n, heads, dh):
+@pytest.mark.parametrize("B,n,heads,dh", [(2, 50, 2, 32), (1, 432, 3, 64), (2, 130, 2, 64), (1, 216, 2, 32), (1, 300, 1, 32)])
+def test_attention_global(ops, dtype, B, n, heads, dh, valu):
+    _set_attn_impl(valu)
     dim = heads * dh
     qkv, qh = dev(rnd((B, n, 3 * dim), 1), dtype, True)
     scale = dh ** -0.5
@@ -235,14 +242,17 @@ def test_attention_global(ops, dtype, B, n, heads, dh):
     close(y, ref, dtype, "y")
     gy, gyh = dev(rnd((B, n, dim), 2), dtype)
     y.backward(gy)
+    _set_attn_impl(False)
     ref.backward(gyh)
     close(qkv.grad, qr.grad, dtype, "gqkv")
 
 
+@pytest.mark.parametrize("valu", [False, True])
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("part", [1, 2])
-def test_attention_window(ops, dtype, part):
+def test_attention_window(ops, dtype, part, valu):
     from oracle import ctunet_oracle as O
+    _set_attn_impl(valu)
     B, D, H, W, heads, dh, win = 1, 6, 12, 12, 2, 32, 6
     dim = heads * dh
     qkv, qh = dev(rnd((B, D, H, W, 3 * dim), 1), dtype, True)
@@ -259,6 +269,7 @@ def test_attention_window(ops, dtype, part):
     close(y, ref, dtype, "y")
     gy, gyh = dev(rnd((B, D, H, W, dim), 3), dtype)
     y.backward(gy)
+    _set_attn_impl(False)
     ref.backward(gyh)
     close(qkv.grad, qr.grad, dtype, "gqkv")
     close(table.grad, tr.grad, dtype, "gbias")
