@@ -62,6 +62,20 @@ class KernelTimer:
         else:
             flops = 2.0 * rows_out * g.N * k * taps
         self.rec.append((name, flops, e0, e1))
+        self.shape[len(self.rec) - 1] = f"{name[4:]} M={rows_out} N={g.N} K={k} taps={taps} s={g.sd}{g.sh}{g.sw} mode={g.mode}"
+
+    shape = {}
+
+    def by_shape(self, top=25):
+        agg = {}
+        for i, (name, flops, e0, e1) in enumerate(self.rec):
+            key = self.shape.get(i, name)
+            a = agg.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1)
+            a[2] += flops
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]
+        return [f"{v[1]:8.2f} ms  x{v[0]:3d}  {v[2] / max(v[1], 1e-9) / 1e9:8.1f} TFLOP/s  {k}" for k, v in rows]
 
     def summary(self):
         out = {}
@@ -176,6 +190,8 @@ def main():
         torch.cuda.synchronize()
         _lib.PROFILER = None
         s = timer.summary()
+        if os.environ.get("CTU_BENCH_SHAPES"):
+            print("\n".join(timer.by_shape()), file=sys.stderr, flush=True)
         dom = max(s, key=lambda k: s[k]["ms"])
         tot = {k: round(v["ms"] / 2, 3) for k, v in s.items()}
         ach = s[dom]["flops"] / (s[dom]["ms"] * 1e-3) / 1e12

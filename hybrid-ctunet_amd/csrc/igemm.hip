@@ -21,6 +21,8 @@ struct NtArgs {
   ctu_geom g;
   ctu_epilogue ep;
   int M, K, taps, kchunks, tiles_n, nwg;
+  int splitk, its_per_split;
+  float* ws;
 };
 
 template <typename T, int BN>
@@ -120,12 +122,14 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int n_it = p.taps * p.kchunks;
-  load_tiles(0);
+  // split-K: blockIdx.y owns a contiguous range of (tap, k-chunk) iterations; partial tiles are summed in `ws`
+  const int it0 = blockIdx.y * p.its_per_split;
+  const int n_it = min(p.taps * p.kchunks, it0 + p.its_per_split);
+  load_tiles(it0);
   store_tiles(0);
   __syncthreads();
-  for (int it = 0; it < n_it; ++it) {
-    const int buf = it & 1;
+  for (int it = it0; it < n_it; ++it) {
+    const int buf = (it - it0) & 1;
     if (it + 1 < n_it) load_tiles(it + 1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -163,6 +167,18 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtArgs p) {
         stage[row * STAGE_LD + j * 32 + r] = acc[i][j][e];
       }
     __syncthreads();
+    if (p.splitk > 1) {
+      // partial sums -> fp32 workspace; each wave instruction adds 64 consecutive floats of one row (256 B: the shape
+      // global float atomics run at full rate for); the epilogue proper runs in splitk_finish_kernel
+      for (int idx = lane; idx < 32 * WN; idx += 64) {
+        const int row = idx / WN, col = idx % WN;
+        const int m = m0 + wm * 64 + i * 32 + row;
+        const int n = n0 + wn * WN + col;
+        if (m < M && n < N) atomicAdd(p.ws + (size_t)m * N + n, stage[row * STAGE_LD + col]);
+      }
+      __syncthreads();
+      continue;
+    }
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
       const int v = lane + 64 * q;
@@ -214,6 +230,36 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtArgs p) {
   }
 }
 
+// epilogue of a split-K GEMM: out = act(ws + bias) + residual, ws fp32 [M][N]
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, T* __restrict__ out,
+                                                            const float* __restrict__ bias, const T* __restrict__ res,
+                                                            const int act, const int M, const int N, const int ldc) {
+  const int ncg = N >> 3;
+  const int64_t nvec = (int64_t)M * ncg;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / ncg;
+    const int n = (int)(i - m * ncg) * 8;
+    float x[8];
+    load8(ws + m * N + n, x);
+    if (bias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] += bias[n + e];
+    }
+    if (act == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = gelu_erf(x[e]);
+    }
+    if (res) {
+      float rr[8];
+      load8(res + m * ldc + n, rr);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] += rr[e];
+    }
+    store8(out + m * ldc + n, x);
+  }
+}
+
 template <typename T>
 static int launch_nt(const void* a1, const void* a2, const void* w, void* out, const ctu_geom* g,
                      const ctu_epilogue* ep, hipStream_t stream) {
@@ -225,14 +271,25 @@ static int launch_nt(const void* a1, const void* a2, const void* w, void* out, c
   p.taps = g->kd * g->kh * g->kw;
   p.kchunks = (p.K + 31) / 32;
   const int tiles_m = (p.M + 127) / 128;
+  const int n_it = p.taps * p.kchunks;
+  p.splitk = (ep->splitk > 1 && ep->splitk_ws) ? (ep->splitk < n_it ? ep->splitk : n_it) : 1;
+  p.its_per_split = (n_it + p.splitk - 1) / p.splitk;
+  p.splitk = (n_it + p.its_per_split - 1) / p.its_per_split;
+  p.ws = ep->splitk_ws;
   if (g->N <= 64) {
     p.tiles_n = (g->N + 63) / 64;
     p.nwg = tiles_m * p.tiles_n;
-    hipLaunchKernelGGL((igemm_nt_kernel<T, 64>), dim3(p.nwg), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((igemm_nt_kernel<T, 64>), dim3(p.nwg, p.splitk), dim3(256), 0, stream, p);
   } else {
     p.tiles_n = (g->N + 127) / 128;
     p.nwg = tiles_m * p.tiles_n;
-    hipLaunchKernelGGL((igemm_nt_kernel<T, 128>), dim3(p.nwg), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((igemm_nt_kernel<T, 128>), dim3(p.nwg, p.splitk), dim3(256), 0, stream, p);
+  }
+  if (p.splitk > 1) {
+    const int64_t nvec = (int64_t)p.M * (g->N / 8);
+    hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3(grid_for(nvec, 256)), dim3(256), 0, stream, p.ws,
+                       reinterpret_cast<T*>(out), ep->bias, reinterpret_cast<const T*>(ep->residual), ep->act, p.M, g->N,
+                       ep->ldc);
   }
   return ctu_check_launch("igemm_nt");
 }
@@ -268,6 +325,8 @@ extern "C" int ctu_igemm_nt(ctu_dtype dtype, const void* a1, const void* a2, con
                 "scatter grid mismatch");
     CTU_REQUIRE(ep->n_split == 0, "scatter and split are exclusive");
   }
+  CTU_REQUIRE(ep->splitk <= 1 || (ep->splitk_ws && !ep->scatter && ep->n_split == 0),
+              "split-K needs a zeroed fp32 workspace and a plain (non-scatter, single destination) epilogue");
   CTU_DISPATCH(dtype, return launch_nt<float>(a1, a2, w, out, g, ep, (hipStream_t)stream),
                return launch_nt<bf16>(a1, a2, w, out, g, ep, (hipStream_t)stream));
 }
@@ -406,17 +465,30 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnArgs a) {
       buf ^= 1;
     }
   }
-  // every wave adds its partial tile (its 16-row slices) into the fp32 panel
+  // the four waves hold partial tiles over different 16-row slices: sum them in LDS (ds_add_f32), then ONE global
+  // update per element and workgroup (global float atomics run at ~1.3 TB/s chip-wide: 4x fewer bytes matter)
+  static_assert(sizeof(sP) >= (size_t)TN * TC * sizeof(float), "reduction tile must fit in sP");
+  float* red = reinterpret_cast<float*>(&sP[0][0]);
+  __syncthreads();
+  for (int i = tid; i < TN * TC; i += 256) red[i] = 0.f;
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < TJ; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int n = n0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int c = c0 + j * 32 + r;
-        if (n < N && c < C) atomicAdd(&a.dw[((size_t)tap * N + n) * C + c], acc[i][j][e]);
-      }
+      for (int e = 0; e < 16; ++e)
+        atomicAdd(&red[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * TC + j * 32 + r], acc[i][j][e]);
+  __syncthreads();
+  const bool single = gridDim.z == 1;
+  for (int i = tid; i < TN * TC; i += 256) {
+    const int n = n0 + i / TC, c = c0 + i % TC;
+    if (n < N && c < C) {
+      float* dst = &a.dw[((size_t)tap * N + n) * C + c];
+      if (single) *dst += red[i];  // sole writer of this element
+      else atomicAdd(dst, red[i]);
+    }
+  }
 }
 
 static unsigned long long magic32(int d) { return ((1ull << 32) + (unsigned long long)d - 1) / (unsigned long long)d; }
@@ -435,7 +507,8 @@ static int launch_tn(const void* p, int ldp, const void* q1, const void* q2, flo
   const int tiles_n = (g->N + TN - 1) / TN;
   a.tiles_c = (a.C + TC - 1) / TC;
   const int tiles = tiles_n * a.tiles_c * a.taps;
-  int splits = (2048 + tiles - 1) / tiles;
+  // ~3 workgroups per CU in total; no K split at all once the tiles alone fill the chip
+  int splits = tiles >= 512 ? 1 : (768 + tiles - 1) / tiles;
   const int max_splits = (a.M + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

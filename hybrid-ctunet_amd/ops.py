@@ -73,8 +73,19 @@ def _plain_geom(M, K, N) -> Geom:
     return _geom(1, (M, 1, 1), (M, 1, 1), K, 0, N)
 
 
-def _epi(ldc, bias=None, residual=None, act=0, out2=None, n_split=0, ldc2=0, scatter=None) -> Epilogue:
+def _splitk_for(M: int, N: int, K: int) -> int:
+    """Split-K factor for a plain GEMM: few output tiles (the 864-token ViT trunk) and a long reduction."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 128 or K < 512:
+        return 1
+    return max(1, min(16, K // 128, 512 // tiles))
+
+
+def _epi(ldc, bias=None, residual=None, act=0, out2=None, n_split=0, ldc2=0, scatter=None, splitk_ws=None,
+         splitk=1) -> Epilogue:
     e = Epilogue()
+    e.splitk = splitk if splitk_ws is not None else 1
+    e.splitk_ws = ptr(splitk_ws)
     e.bias = ptr(bias)
     e.residual = ptr(residual)
     e.act = act
@@ -107,6 +118,14 @@ def _igemm_tn(p, ldp, q1, q2, dw, g: Geom):
     call("ctu_igemm_tn", dcode(p.dtype), ptr(p), ldp, ptr(q1), ptr(q2), ptr(dw), g, stream())
 
 
+def _plain_gemm(x, w, out, M, K, N, bias=None, residual=None, act=0):
+    """out[M,N] = act(x[M,K] @ w[N,K]^T + bias) + residual, with split-K when there are few tiles and a long K."""
+    sk = _splitk_for(M, N, K)
+    ws = torch.zeros((M, N), dtype=torch.float32, device=x.device) if sk > 1 else None
+    _igemm_nt(x, None, w, out, _plain_geom(M, K, N),
+              _epi(N, bias=bias, residual=residual, act=act, splitk_ws=ws, splitk=sk))
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x @ W^T + b) (+ residual).  x: [..., K]; W: [N, K] fp32 (nn.Linear / 1x1x1 conv layout).
     Reference: nn.Linear at vit.py:36,39,59,62,117 and hybrid_CTUNet.py:402,457,465,519,522,632-633,641,679;
@@ -125,12 +144,12 @@ class LinearFn(torch.autograd.Function):
         if act == 1 and any(ctx.needs_input_grad[:3]):
             # keep the pre-activation for GELU'
             pre = torch.empty_like(out)
-            _igemm_nt(x, None, wf, pre, _plain_geom(M, K, N), _epi(N, bias=bias))
+            _plain_gemm(x, wf, pre, M, K, N, bias=bias)
             call("ctu_gelu_fwd", dcode(x.dtype), ptr(pre), ptr(out), out.numel(), stream())
             if residual is not None:
                 call("ctu_add", dcode(x.dtype), ptr(out), ptr(residual), ptr(out), out.numel(), stream())
         else:
-            _igemm_nt(x, None, wf, out, _plain_geom(M, K, N), _epi(N, bias=bias, residual=residual, act=act))
+            _plain_gemm(x, wf, out, M, K, N, bias=bias, residual=residual, act=act)
         ctx.save_for_backward(x, weight, pre)
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
@@ -152,7 +171,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wd = _packed(weight, "lin_d", x.dtype, lambda: weight.detach().reshape(N, K).t().to(x.dtype).contiguous())
             gx = torch.empty_like(x)
-            _igemm_nt(g, None, wd, gx, _plain_geom(M, N, K), _epi(K))
+            _plain_gemm(g, wd, gx, M, N, K)
         if ctx.needs_input_grad[1]:
             gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
             _igemm_tn(g, N, x, None, gw, _plain_geom(M, K, N))

@@ -73,6 +73,11 @@ typedef struct ctu_epilogue {
   int32_t scatter;
   int32_t n_per_tap;
   int32_t sc_D, sc_H, sc_W, sc_kd, sc_kh, sc_kw;
+  /* split-K for GEMMs with few output tiles and a long reduction (the ViT trunk: 864 tokens, K up to 3072):
+   * splitk > 1 with a ZEROED fp32 workspace [M][N] makes `splitk` workgroups per tile sum partial tiles into the
+   * workspace; a second kernel applies bias/act/residual and writes `out`.  Plain epilogue only. */
+  int32_t splitk;
+  float* splitk_ws;
 } ctu_epilogue;
 
 /* K1/K3/K5/K2/K4 forward and data-gradient:  out[m][n] = sum_tap sum_c A[gather(m,tap)][c] * W[tap][n][c]
