@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const T* __restrict_
             const int kbase = (kc + t) * 32 + 16 * sh + 4 * h;
 #pragma unroll
             for (int dt = 0; dt < DH / 32; ++dt)
-              Mma<T>::mma(FragOps<T>::gather_perm(&Vs[kbase * LD + dt * 32 + r], LD), fb, oacc[dt]);
+              Mma<T>::mma(Mma<T>::gather_perm(&Vs[kbase * LD + dt * 32 + r], LD), fb, oacc[dt]);
           }
         }
       }
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(const T* __restric
         const int kbase = kt * 32 + 16 * sh + 4 * h;
 #pragma unroll
         for (int dt = 0; dt < DH / 32; ++dt)
-          Mma<T>::mma(FragOps<T>::gather_perm(&Ks[kbase * LD + dt * 32 + r], LD), fb, dq[dt]);
+          Mma<T>::mma(Mma<T>::gather_perm(&Ks[kbase * LD + dt * 32 + r], LD), fb, dq[dt]);
       }
     }
     if (qok) {
@@ -387,8 +387,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(const T* __restri
         const int qbase = qt * 32 + 16 * sh + 4 * h;
 #pragma unroll
         for (int dt = 0; dt < DH / 32; ++dt) {
-          Mma<T>::mma(FragOps<T>::gather_perm(&Gs[qbase * LD + dt * 32 + r], LD), fp, dv[dt]);
-          Mma<T>::mma(FragOps<T>::gather_perm(&Qs[qbase * LD + dt * 32 + r], LD), fd, dk[dt]);
+          Mma<T>::mma(Mma<T>::gather_perm(&Gs[qbase * LD + dt * 32 + r], LD), fp, dv[dt]);
+          Mma<T>::mma(Mma<T>::gather_perm(&Qs[qbase * LD + dt * 32 + r], LD), fd, dk[dt]);
         }
       }
     }

@@ -10,13 +10,25 @@ template <typename T> struct Mma;
 template <> struct Mma<bf16> {
   typedef bf16x8 Frag;
   static __device__ __forceinline__ Frag load(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
-  // k-strided gather (transposed operand): element j at p[j*stride]
-  static __device__ __forceinline__ Frag gather(const bf16* p, int stride) {
+  // k-strided gather (transposed operand) from LDS: element j at p[j*stride], where p is THIS lane's pointer
+  // &M[k0 + 8h][c0 + r].  Done with two ds_read_b64_tr_b16: per 16-lane group the instruction reads a 4(k) x 16(c) block
+  // and hands lane i column i; lane 4q+pp of the group must supply the address of block row q, columns 4pp..4pp+3,
+  // i.e. its own pointer moved by q rows and (3pp - 4q) columns.  Needs EXEC all ones, (c0, stride) multiples of 4.
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+  typedef __attribute__((address_space(3))) bf16x4_* lds_v4_ptr;
+  static __device__ __forceinline__ Frag gather2(const bf16* p, int stride, int second_rows) {
+    const int i = threadIdx.x & 15, q = i >> 2, pp = i & 3;
+    const bf16* a0 = p + q * stride + 3 * pp - 4 * q;
+    const bf16x4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_ptr)a0);
+    const bf16x4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_ptr)(a0 + second_rows * stride));
     Frag f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = p[j * stride];
+    for (int j = 0; j < 4; ++j) { f[j] = lo[j]; f[4 + j] = hi[j]; }
     return f;
   }
+  static __device__ __forceinline__ Frag gather(const bf16* p, int stride) { return gather2(p, stride, 4); }
+  // rows +0..3 and +8..11: the order in which an accumulator tile presents itself as the other MFMA operand
+  static __device__ __forceinline__ Frag gather_perm(const bf16* p, int stride) { return gather2(p, stride, 8); }
   static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
@@ -36,6 +48,12 @@ template <> struct Mma<float> {
     Frag f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) f.v[j] = p[j * stride];
+    return f;
+  }
+  static __device__ __forceinline__ Frag gather_perm(const float* p, int stride) {
+    Frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = p[((j & 3) + 8 * (j >> 2)) * stride];
     return f;
   }
   // 32x32x2: lane (r,h) supplies A[r][k=h], B[k=h][r]; step j pairs k = j (h=0) with k = 8+j (h=1) on both operands
