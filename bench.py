@@ -51,7 +51,7 @@ class KernelTimer:
             B, D, H, W, C1, C2, N = args[5:12]
             self.rec.append((name, 2.0 * B * D * H * W * N * (C1 + C2) * 27, e0, e1))
             return
-        g = args[5] if name == "ctu_igemm_nt" else args[6]
+        g = args[5] if name == "ctu_igemm_nt" else args[7]  # (dtype, p, ldp, q1, q2, dw, bias_grad, geom, stream)
         taps = g.kd * g.kh * g.kw
         rows_out = g.B * g.Do * g.Ho * g.Wo
         rows_in = g.B * g.Di * g.Hi * g.Wi

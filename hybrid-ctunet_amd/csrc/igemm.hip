@@ -339,6 +339,7 @@ struct TnArgs {
   const void* q1;
   const void* q2;
   float* dw;
+  float* bias_grad;  // optional: [N] += column sums of P (bias gradient), computed from the staged P vectors
   ctu_geom g;
   int ldp, M, C, taps, rows_per_split, tiles_c;
   unsigned long long magic_w, magic_h, magic_d;  // ceil(2^32 / d)
@@ -382,6 +383,11 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnArgs a) {
   const int q_part = tid % VQ, q_row = tid / VQ;
   u32x4 rp[NP], rq[NQ];
 
+  // bias gradient: the workgroups of c-tile 0 / tap 0 sum the P columns they stage (this thread's EV fixed columns)
+  const bool do_bias = a.bias_grad != nullptr && (blockIdx.x % a.tiles_c) == 0 && tap == 0;
+  float bsum[EV];
+#pragma unroll
+  for (int e = 0; e < EV; ++e) bsum[e] = 0.f;
   auto load_tiles = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -391,6 +397,11 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnArgs a) {
       const int n = n0 + p_part * EV;
       if (row < BKM && m < m_end && n < N) v = *reinterpret_cast<const u32x4*>(P + (size_t)m * a.ldp + n);
       rp[i] = v;
+      if (do_bias) {
+        const T* pv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int e = 0; e < EV; ++e) bsum[e] += (float)pv[e];
+      }
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -470,6 +481,16 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnArgs a) {
   static_assert(sizeof(sP) >= (size_t)TN * TC * sizeof(float), "reduction tile must fit in sP");
   float* red = reinterpret_cast<float*>(&sP[0][0]);
   __syncthreads();
+  if (do_bias) {  // block-uniform
+    __shared__ float bred[TN];
+    if (tid < TN) bred[tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EV; ++e) atomicAdd(&bred[p_part * EV + e], bsum[e]);
+    __syncthreads();
+    if (tid < TN && n0 + tid < N) atomicAdd(&a.bias_grad[n0 + tid], bred[tid]);
+    __syncthreads();
+  }
   for (int i = tid; i < TN * TC; i += 256) red[i] = 0.f;
   __syncthreads();
 #pragma unroll
@@ -494,10 +515,10 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnArgs a) {
 static unsigned long long magic32(int d) { return ((1ull << 32) + (unsigned long long)d - 1) / (unsigned long long)d; }
 
 template <typename T>
-static int launch_tn(const void* p, int ldp, const void* q1, const void* q2, float* dw, const ctu_geom* g,
-                     hipStream_t stream) {
+static int launch_tn(const void* p, int ldp, const void* q1, const void* q2, float* dw, float* bias_grad,
+                     const ctu_geom* g, hipStream_t stream) {
   TnArgs a;
-  a.p = p; a.q1 = q1; a.q2 = q2; a.dw = dw; a.g = *g; a.ldp = ldp;
+  a.p = p; a.q1 = q1; a.q2 = q2; a.dw = dw; a.bias_grad = bias_grad; a.g = *g; a.ldp = ldp;
   a.M = (int)((int64_t)g->B * g->Do * g->Ho * g->Wo);
   a.C = g->C1 + g->C2;
   a.taps = g->kd * g->kh * g->kw;
@@ -526,14 +547,14 @@ static int launch_tn(const void* p, int ldp, const void* q1, const void* q2, flo
 }
 
 extern "C" int ctu_igemm_tn(ctu_dtype dtype, const void* p, int32_t ldp, const void* q1, const void* q2, float* dw,
-                            const ctu_geom* g, ctu_stream_t stream) {
+                            float* bias_grad, const ctu_geom* g, ctu_stream_t stream) {
   if (int rc = check_geom(g)) return rc;
   CTU_REQUIRE(p && q1 && dw, "null pointer");
   CTU_REQUIRE(g->C2 == 0 || q2, "C2 > 0 needs q2");
   CTU_REQUIRE(ldp >= g->N && ldp % 8 == 0, "ldp must be >= N and a multiple of 8");
   CTU_REQUIRE(g->kd * g->kh * g->kw <= 65535, "too many taps");
-  CTU_DISPATCH(dtype, return launch_tn<float>(p, ldp, q1, q2, dw, g, (hipStream_t)stream),
-               return launch_tn<bf16>(p, ldp, q1, q2, dw, g, (hipStream_t)stream));
+  CTU_DISPATCH(dtype, return launch_tn<float>(p, ldp, q1, q2, dw, bias_grad, g, (hipStream_t)stream),
+               return launch_tn<bf16>(p, ldp, q1, q2, dw, bias_grad, g, (hipStream_t)stream));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -611,24 +632,24 @@ __global__ __launch_bounds__(64 * KD) void conv_cin1_wgrad_kernel(const T* __res
   int oh = t % g.Ho; t /= g.Ho;
   int od = t % g.Do;
   int b = t / g.Do;
+  // lane l < KH*KW fetches patch element (l / KW, l % KW) of this wave's kd plane: ONE vector load per row instead of
+  // KH*KW same-address loads; the values are then broadcast with v_readlane (compile-time lane index)
+  const int pth = lane / KW, ptw = lane % KW;
   for (int m = m_begin; m < m_end; ++m) {
     const float d = (float)dy[(size_t)m * g.N + nb + lane];
     const int id = od * g.sd - g.pd + td;
-    if ((unsigned)id < (unsigned)g.Di) {
-#pragma unroll
-      for (int th = 0; th < KH; ++th) {
-        const int ih = oh * g.sh - g.ph + th;
-        if ((unsigned)ih < (unsigned)g.Hi) {
-          const T* xrow = x + (((size_t)b * g.Di + id) * g.Hi + ih) * g.Wi;
-#pragma unroll
-          for (int tw = 0; tw < KW; ++tw) {
-            const int iw = ow * g.sw - g.pw + tw;
-            const float xv = ((unsigned)iw < (unsigned)g.Wi) ? (float)xrow[iw] : 0.f;
-            acc[th][tw] = fmaf(d, xv, acc[th][tw]);
-          }
-        }
-      }
+    float xl = 0.f;
+    if (lane < KH * KW && (unsigned)id < (unsigned)g.Di) {
+      const int ih = oh * g.sh - g.ph + pth, iw = ow * g.sw - g.pw + ptw;
+      if ((unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi)
+        xl = (float)x[((((size_t)b * g.Di + id) * g.Hi + ih) * g.Wi) + iw];
     }
+    const int xbits = __float_as_int(xl);
+#pragma unroll
+    for (int th = 0; th < KH; ++th)
+#pragma unroll
+      for (int tw = 0; tw < KW; ++tw)
+        acc[th][tw] = fmaf(d, __int_as_float(__builtin_amdgcn_readlane(xbits, th * KW + tw)), acc[th][tw]);
     if (++ow == g.Wo) {
       ow = 0;
       if (++oh == g.Ho) {

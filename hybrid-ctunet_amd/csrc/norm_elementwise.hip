@@ -130,16 +130,24 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
       const size_t off = base + (size_t)s * C;
       load8(dy + off, g);
       load8(x + off, xv);
-      if (act) {
-        float yv[8];
-        load8(y + off, yv);
+      float xh[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = yv[e] > 0.f ? g[e] : g[e] * LRELU_SLOPE;
+      for (int e = 0; e < 8; ++e) xh[e] = (xv[e] - mean[e]) * rstd[e];
+      if (act) {
+        if (y) {  // residual case: the activation saw xhat + residual, whose sign only y records
+          float yv[8];
+          load8(y + off, yv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] = yv[e] > 0.f ? g[e] : g[e] * LRELU_SLOPE;
+        } else {  // no residual: sign(y) == sign(xhat), no third input stream
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] = xh[e] > 0.f ? g[e] : g[e] * LRELU_SLOPE;
+        }
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         s1[e] += (double)g[e];
-        s2[e] += (double)g[e] * (double)((xv[e] - mean[e]) * rstd[e]);
+        s2[e] += (double)g[e] * (double)xh[e];
       }
     }
   }
@@ -172,10 +180,15 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
     load8(dy + i * 8, g);
     load8(x + i * 8, xv);
     if (act) {
-      float yv[8];
-      load8(y + i * 8, yv);
+      if (y) {
+        float yv[8];
+        load8(y + i * 8, yv);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) g[e] = yv[e] > 0.f ? g[e] : g[e] * LRELU_SLOPE;
+        for (int e = 0; e < 8; ++e) g[e] = yv[e] > 0.f ? g[e] : g[e] * LRELU_SLOPE;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = (xv[e] - mean[e]) * rstd[e] > 0.f ? g[e] : g[e] * LRELU_SLOPE;
+      }
     }
     if (dres) store8(dres + i * 8, g);
     float o[8];
@@ -242,7 +255,7 @@ extern "C" int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, 
 extern "C" int ctu_in_bwd_reduce(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
                                  double* sums, int32_t B, int64_t S, int32_t C, int32_t act, ctu_stream_t stream) {
   if (int rc = check_in(x, B, S, C)) return rc;
-  CTU_REQUIRE(dy && stats && sums && (y || !act), "null pointer");
+  CTU_REQUIRE(dy && stats && sums, "null pointer");  // y == NULL: no residual was added (sign taken from xhat)
   const int64_t rows = in_rows_per_block(S, B);
   dim3 grid((unsigned)((S + rows - 1) / rows), B);
   hipStream_t s = (hipStream_t)stream;
@@ -258,7 +271,7 @@ extern "C" int ctu_in_bwd_apply(ctu_dtype dtype, const void* dy, const void* x, 
                                 const double* sums, void* dx, void* dres, int32_t B, int64_t S, int32_t C, int32_t act,
                                 ctu_stream_t stream) {
   if (int rc = check_in(x, B, S, C)) return rc;
-  CTU_REQUIRE(dy && stats && sums && dx && (y || !act), "null pointer");
+  CTU_REQUIRE(dy && stats && sums && dx, "null pointer");
   const unsigned grid = grid_for((int64_t)B * S * (C / 8), 256);
   hipStream_t s = (hipStream_t)stream;
   CTU_DISPATCH(dtype,
@@ -274,7 +287,7 @@ extern "C" int ctu_in_bwd_apply(ctu_dtype dtype, const void* dy, const void* x, 
 // of 8 per lane (dim <= LPR*32).  dim = LPR * VPL * 8.
 // =========================================================================================================
 #define LN_MAXV 4
-template <typename T>
+template <typename T, int VPL>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             float* __restrict__ mean_rstd, const int64_t rows,
@@ -284,10 +297,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   const int sub = tid % lpr, rloc = tid / lpr;
   const float inv_d = 1.0f / (float)dim;
   for (int64_t row = (int64_t)blockIdx.x * rows_per_block + rloc; row < rows; row += (int64_t)gridDim.x * rows_per_block) {
-    float v[LN_MAXV][8];
+    float v[VPL][8];
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k)
+    for (int k = 0; k < VPL; ++k)
       if (k < vpl) {
         load8(x + (size_t)row * dim + (size_t)(sub + k * lpr) * 8, v[k]);
 #pragma unroll
@@ -296,14 +309,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     const float mu = group_sum(s, lpr) * inv_d;
     float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k)
+    for (int k = 0; k < VPL; ++k)
       if (k < vpl) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mu; q = fmaf(d, d, q); }
       }
     const float rstd = rsqrtf(group_sum(q, lpr) * inv_d + NORM_EPS);
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k)
+    for (int k = 0; k < VPL; ++k)
       if (k < vpl) {
         const int c0 = (sub + k * lpr) * 8;
         float o[8];
@@ -315,7 +328,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   }
 }
 
-template <typename T>
+template <typename T, int VPL>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean_rstd, T* __restrict__ dx,
@@ -326,17 +339,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   const int rows_per_block = 256 / lpr;
   const int sub = tid % lpr, rloc = tid / lpr;
   const float inv_d = 1.0f / (float)dim;
-  float ag[LN_MAXV][8], ab[LN_MAXV][8];
+  float ag[VPL][8], ab[VPL][8];
 #pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k)
+  for (int k = 0; k < VPL; ++k)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; }
   for (int64_t row = (int64_t)blockIdx.x * rows_per_block + rloc; row < rows; row += (int64_t)gridDim.x * rows_per_block) {
     const float mu = mean_rstd[row * 2], rstd = mean_rstd[row * 2 + 1];
-    float g[LN_MAXV][8], xh[LN_MAXV][8];
+    float g[VPL][8], xh[VPL][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k)
+    for (int k = 0; k < VPL; ++k)
       if (k < vpl) {
         const int c0 = (sub + k * lpr) * 8;
         float d[8], xv[8];
@@ -354,7 +367,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       }
     const float m1 = group_sum(s1, lpr) * inv_d, m2 = group_sum(s2, lpr) * inv_d;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k)
+    for (int k = 0; k < VPL; ++k)
       if (k < vpl) {
         const int c0 = (sub + k * lpr) * 8;
         float o[8];
@@ -365,7 +378,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
   // column sums: reduce the block's row lanes through LDS, then one atomic per column per block
   __shared__ float red[256 * 8];
-  for (int k = 0; k < LN_MAXV; ++k) {
+  for (int k = 0; k < VPL; ++k) {
     if (k >= vpl) break;
     for (int which = 0; which < 2; ++which) {
       __syncthreads();
@@ -405,11 +418,15 @@ extern "C" int ctu_layernorm_fwd(ctu_dtype dtype, const void* x, const float* ga
   CTU_REQUIRE(x && gamma && beta && y && mean_rstd && rows > 0, "null pointer / bad rows");
   const unsigned grid = grid_for(rows, 256 / lpr, 4096);
   hipStream_t s = (hipStream_t)stream;
-  CTU_DISPATCH(dtype,
-               hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, gamma, beta,
-                                  (float*)y, mean_rstd, rows, dim, lpr, vpl),
-               hipLaunchKernelGGL(layernorm_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, gamma, beta,
-                                  (bf16*)y, mean_rstd, rows, dim, lpr, vpl));
+#define LN_FWD(T, V) \
+  hipLaunchKernelGGL((layernorm_fwd_kernel<T, V>), dim3(grid), dim3(256), 0, s, (const T*)x, gamma, beta, (T*)y, mean_rstd, rows, dim, lpr, vpl)
+  switch (vpl) {  // vectors per lane as a template argument: register arrays sized exactly (occupancy)
+    case 1: CTU_DISPATCH(dtype, LN_FWD(float, 1), LN_FWD(bf16, 1)); break;
+    case 2: CTU_DISPATCH(dtype, LN_FWD(float, 2), LN_FWD(bf16, 2)); break;
+    case 3: CTU_DISPATCH(dtype, LN_FWD(float, 3), LN_FWD(bf16, 3)); break;
+    default: CTU_DISPATCH(dtype, LN_FWD(float, 4), LN_FWD(bf16, 4)); break;
+  }
+#undef LN_FWD
   return ctu_check_launch("layernorm_fwd");
 }
 
@@ -421,11 +438,16 @@ extern "C" int ctu_layernorm_bwd(ctu_dtype dtype, const void* dy, const void* x,
   CTU_REQUIRE(dy && x && gamma && mean_rstd && dx && dgamma && dbeta && rows > 0, "null pointer / bad rows");
   const unsigned grid = grid_for(rows, 256 / lpr, 1024);
   hipStream_t s = (hipStream_t)stream;
-  CTU_DISPATCH(dtype,
-               hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy,
-                                  (const float*)x, gamma, mean_rstd, (float*)dx, dgamma, dbeta, rows, dim, lpr, vpl),
-               hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)dy,
-                                  (const bf16*)x, gamma, mean_rstd, (bf16*)dx, dgamma, dbeta, rows, dim, lpr, vpl));
+#define LN_BWD(T, V)                                                                                                  \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<T, V>), dim3(grid), dim3(256), 0, s, (const T*)dy, (const T*)x, gamma, mean_rstd, \
+                     (T*)dx, dgamma, dbeta, rows, dim, lpr, vpl)
+  switch (vpl) {
+    case 1: CTU_DISPATCH(dtype, LN_BWD(float, 1), LN_BWD(bf16, 1)); break;
+    case 2: CTU_DISPATCH(dtype, LN_BWD(float, 2), LN_BWD(bf16, 2)); break;
+    case 3: CTU_DISPATCH(dtype, LN_BWD(float, 3), LN_BWD(bf16, 3)); break;
+    default: CTU_DISPATCH(dtype, LN_BWD(float, 4), LN_BWD(bf16, 4)); break;
+  }
+#undef LN_BWD
   return ctu_check_launch("layernorm_bwd");
 }
 

@@ -114,8 +114,8 @@ def _igemm_nt(x1, x2, w, out, g: Geom, e: Epilogue):
     call("ctu_igemm_nt", dcode(x1.dtype), ptr(x1), ptr(x2), ptr(w), ptr(out), g, e, stream())
 
 
-def _igemm_tn(p, ldp, q1, q2, dw, g: Geom):
-    call("ctu_igemm_tn", dcode(p.dtype), ptr(p), ldp, ptr(q1), ptr(q2), ptr(dw), g, stream())
+def _igemm_tn(p, ldp, q1, q2, dw, g: Geom, bias_grad=None):
+    call("ctu_igemm_tn", dcode(p.dtype), ptr(p), ldp, ptr(q1), ptr(q2), ptr(dw), ptr(bias_grad), g, stream())
 
 
 def _plain_gemm(x, w, out, M, K, N, bias=None, residual=None, act=0):
@@ -172,11 +172,13 @@ class LinearFn(torch.autograd.Function):
             wd = _packed(weight, "lin_d", x.dtype, lambda: weight.detach().reshape(N, K).t().to(x.dtype).contiguous())
             gx = torch.empty_like(x)
             _plain_gemm(g, wd, gx, M, N, K)
+        want_gb = ctx.has_bias and ctx.needs_input_grad[2]
+        if want_gb:
+            gb = torch.zeros(N, dtype=torch.float32, device=x.device)
         if ctx.needs_input_grad[1]:
             gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
-            _igemm_tn(g, N, x, None, gw, _plain_geom(M, K, N))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = torch.zeros(N, dtype=torch.float32, device=x.device)
+            _igemm_tn(g, N, x, None, gw, _plain_geom(M, K, N), bias_grad=gb if want_gb else None)  # bias grad rides along
+        elif want_gb:
             call("ctu_colsum", dcode(g.dtype), ptr(g), M, N, N, ptr(gb), stream())
         return gx, gw, gb, gres, None
 
@@ -397,9 +399,10 @@ class InstanceNormFn(torch.autograd.Function):
         dc = dcode(x.dtype)
         call("ctu_in_stats", dc, ptr(x), B, S, C, ptr(acc), ptr(stats), stream())
         call("ctu_in_apply", dc, ptr(x), ptr(stats), ptr(residual), ptr(y), B, S, C, int(act), stream())
-        ctx.save_for_backward(x, y, stats)
-        ctx.act = int(act)
         ctx.has_res = residual is not None
+        # without a residual sign(y) == sign(xhat): backward recomputes the LeakyReLU mask from x and needs no y
+        ctx.save_for_backward(x, y if ctx.has_res else None, stats)
+        ctx.act = int(act)
         return y
 
     @staticmethod

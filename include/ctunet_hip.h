@@ -89,9 +89,11 @@ int ctu_igemm_nt(ctu_dtype dtype, const void* a1, const void* a2, const void* w,
                  const ctu_geom* g, const ctu_epilogue* ep, ctu_stream_t stream);
 
 /* Weight gradient:  dw[tap][n][c] += sum_m P[m][n] * Q[gather(m,tap)][c]   (fp32 atomics into a zeroed panel).
- * P has g->N columns (leading dim ldp) over the row space, Q1/Q2 are the gathered tensors (C1/C2 channels). */
+ * P has g->N columns (leading dim ldp) over the row space, Q1/Q2 are the gathered tensors (C1/C2 channels).
+ * bias_grad (optional, fp32 [N], zeroed): += column sums of P, i.e. the bias gradient of the same layer, computed
+ * from the P vectors the kernel stages anyway (no second pass over dY). */
 int ctu_igemm_tn(ctu_dtype dtype, const void* p, int32_t ldp, const void* q1, const void* q2, float* dw,
-                 const ctu_geom* g, ctu_stream_t stream);
+                 float* bias_grad, const ctu_geom* g, ctu_stream_t stream);
 
 /* Cin == 1 convolutions (vit_encoder0.conv1 1->64 3x3x3, hybrid_CTUNet.py:57-65; ResNet stem 7x7x7 s(2,2,1),
  * resnet.py:150-155).  x: [B][Di][Hi][Wi] ; w: fp32 [taps][N] ; out: [M][N].  kernel 1x1x1 (ResBlock.conv3 shortcut), 3x3x3 or 7x7x7. */
@@ -135,7 +137,8 @@ int ctu_in_stats(ctu_dtype dtype, const void* x, int32_t B, int64_t S, int32_t C
                  ctu_stream_t stream);
 int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, const void* residual, void* y, int32_t B,
                  int64_t S, int32_t C, int32_t act, ctu_stream_t stream);
-/* backward: g = dy * act'(y); sums[b][c] = (sum g, sum g*xhat), fp64, zeroed by caller;
+/* backward: g = dy * act'(y) (y may be NULL when no residual was added: then sign(y) == sign(xhat) and the third
+ * input stream is skipped); sums[b][c] = (sum g, sum g*xhat), fp64, zeroed by caller;
  * dx = rstd*(g - s1/S - xhat*s2/S); dres = g when dres != NULL. */
 int ctu_in_bwd_reduce(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
                       double* sums, int32_t B, int64_t S, int32_t C, int32_t act, ctu_stream_t stream);
