@@ -352,9 +352,14 @@ __device__ __forceinline__ int fast_div(int x, unsigned long long magic, int d) 
   return q;
 }
 
-template <typename T, int TN, int TC>
+// WT = false: the four waves split the 64 rows of an iteration (each holds the whole TN x TC tile; partials summed in
+//              LDS at the end) - for narrow tiles.
+// WT = true : TN = TC = 128 and the four waves split the TILE into 64x64 quadrants, each walking all 64 rows: 16 MFMAs
+//              per wave per barrier instead of 4, operand panels re-read half as often, no cross-wave reduction.
+template <typename T, int TN, int TC, bool WT = false>
 __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnArgs a) {
-  constexpr int BKM = 64;  // rows (voxels) per iteration; wave w reduces rows [16w, 16w+16)
+  static_assert(!WT || (TN == 128 && TC == 128), "wave-tiled mode is the 128x128 tile");
+  constexpr int BKM = 64;  // rows (voxels) per iteration; WT=false: wave w reduces rows [16w, 16w+16)
   constexpr int EV = 16 / sizeof(T);
   constexpr int LDP = TN + EV, LDQ = TC + EV;
   constexpr int VP = TN / EV, VQ = TC / EV;  // vectors per row
@@ -445,11 +450,13 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnArgs a) {
   };
 
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-  f32x16 acc[TI][TJ];
+  constexpr int AI = WT ? 2 : TI, AJ = WT ? 2 : TJ;  // MFMA tiles per wave
+  const int wn = WT ? (wave >> 1) * 64 : 0, wc = WT ? (wave & 1) * 64 : 0;  // this wave's quadrant (WT)
+  f32x16 acc[AI][AJ];
 #pragma unroll
-  for (int i = 0; i < TI; ++i)
+  for (int i = 0; i < AI; ++i)
 #pragma unroll
-    for (int j = 0; j < TJ; ++j)
+    for (int j = 0; j < AJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -461,16 +468,19 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnArgs a) {
     for (int mb = m_begin; mb < m_end; mb += BKM) {
       const bool more = mb + BKM < m_end;
       if (more) load_tiles(mb + BKM);
-      const int krow = wave * 16 + h * 8;
-      typename Mma<T>::Frag fa[TI], fb[TJ];
 #pragma unroll
-      for (int i = 0; i < TI; ++i) fa[i] = Mma<T>::gather(&sP[buf][krow * LDP + i * 32 + r], LDP);
+      for (int ks = 0; ks < (WT ? 4 : 1); ++ks) {
+        const int krow = (WT ? ks : wave) * 16 + h * 8;
+        typename Mma<T>::Frag fa[AI], fb[AJ];
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) fb[j] = Mma<T>::gather(&sQ[buf][krow * LDQ + j * 32 + r], LDQ);
+        for (int i = 0; i < AI; ++i) fa[i] = Mma<T>::gather(&sP[buf][krow * LDP + wn + i * 32 + r], LDP);
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
+        for (int j = 0; j < AJ; ++j) fb[j] = Mma<T>::gather(&sQ[buf][krow * LDQ + wc + j * 32 + r], LDQ);
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+        for (int i = 0; i < AI; ++i)
+#pragma unroll
+          for (int j = 0; j < AJ; ++j) Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+      }
       if (more) store_tiles(buf ^ 1);
       __syncthreads();
       buf ^= 1;
@@ -478,8 +488,9 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnArgs a) {
   }
   // the four waves hold partial tiles over different 16-row slices: sum them in LDS (ds_add_f32), then ONE global
   // update per element and workgroup (global float atomics run at ~1.3 TB/s chip-wide: 4x fewer bytes matter)
-  static_assert(sizeof(sP) >= (size_t)TN * TC * sizeof(float), "reduction tile must fit in sP");
+  static_assert(WT || sizeof(sP) >= (size_t)TN * TC * sizeof(float), "reduction tile must fit in sP");
   float* red = reinterpret_cast<float*>(&sP[0][0]);
+  const bool single = gridDim.z == 1;
   __syncthreads();
   if (do_bias) {  // block-uniform
     __shared__ float bred[TN];
@@ -491,17 +502,34 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnArgs a) {
     if (tid < TN && n0 + tid < N) atomicAdd(&a.bias_grad[n0 + tid], bred[tid]);
     __syncthreads();
   }
+  if constexpr (WT) {
+    // each wave owns its 64x64 quadrant: straight from the accumulators, 128 contiguous bytes per 32 lanes
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+#pragma unroll
+      for (int j = 0; j < AJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int n = n0 + wn + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int c = c0 + wc + j * 32 + r;
+          if (n < N && c < C) {
+            float* dst = &a.dw[((size_t)tap * N + n) * C + c];
+            if (single) *dst += acc[i][j][e];
+            else atomicAdd(dst, acc[i][j][e]);
+          }
+        }
+    return;
+  }
   for (int i = tid; i < TN * TC; i += 256) red[i] = 0.f;
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < TI; ++i)
+  for (int i = 0; i < AI; ++i)
 #pragma unroll
-    for (int j = 0; j < TJ; ++j)
+    for (int j = 0; j < AJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e)
         atomicAdd(&red[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * TC + j * 32 + r], acc[i][j][e]);
   __syncthreads();
-  const bool single = gridDim.z == 1;
   for (int i = tid; i < TN * TC; i += 256) {
     const int n = n0 + i / TC, c = c0 + i % TC;
     if (n < N && c < C) {
@@ -524,12 +552,14 @@ static int launch_tn(const void* p, int ldp, const void* q1, const void* q2, flo
   a.taps = g->kd * g->kh * g->kw;
   a.magic_w = magic32(g->Wo); a.magic_h = magic32(g->Ho); a.magic_d = magic32(g->Do);
   const bool small_n = g->N <= 32, small_c = a.C <= 32;
-  const int TN = small_n ? 32 : 64, TC = small_c ? 32 : 64;
+  const bool big = g->N >= 128 && a.C >= 128;  // 128x128 wave-tiled variant
+  const int TN = big ? 128 : (small_n ? 32 : 64), TC = big ? 128 : (small_c ? 32 : 64);
   const int tiles_n = (g->N + TN - 1) / TN;
   a.tiles_c = (a.C + TC - 1) / TC;
   const int tiles = tiles_n * a.tiles_c * a.taps;
-  // ~3 workgroups per CU in total; no K split at all once the tiles alone fill the chip
-  int splits = tiles >= 512 ? 1 : (768 + tiles - 1) / tiles;
+  // ~2-3 workgroups per CU in total; no K split at all once the tiles alone fill the chip
+  const int target = big ? 512 : 768;
+  int splits = tiles >= target ? 1 : (target + tiles - 1) / tiles;
   const int max_splits = (a.M + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -539,7 +569,8 @@ static int launch_tn(const void* p, int ldp, const void* q1, const void* q2, flo
   splits = (a.M + rps - 1) / rps;
   a.rows_per_split = rps;
   dim3 grid(tiles_n * a.tiles_c, a.taps, splits);
-  if (small_n && small_c) hipLaunchKernelGGL((igemm_tn_kernel<T, 32, 32>), grid, dim3(256), 0, stream, a);
+  if (big) hipLaunchKernelGGL((igemm_tn_kernel<T, 128, 128, true>), grid, dim3(256), 0, stream, a);
+  else if (small_n && small_c) hipLaunchKernelGGL((igemm_tn_kernel<T, 32, 32>), grid, dim3(256), 0, stream, a);
   else if (small_n) hipLaunchKernelGGL((igemm_tn_kernel<T, 32, 64>), grid, dim3(256), 0, stream, a);
   else if (small_c) hipLaunchKernelGGL((igemm_tn_kernel<T, 64, 32>), grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((igemm_tn_kernel<T, 64, 64>), grid, dim3(256), 0, stream, a);

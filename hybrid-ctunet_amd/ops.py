@@ -448,8 +448,9 @@ class LayerNormFn(torch.autograd.Function):
         gx = torch.empty_like(x)
         gg = torch.zeros(dim, dtype=torch.float32, device=x.device)
         gb = torch.zeros(dim, dtype=torch.float32, device=x.device)
-        call("ctu_layernorm_bwd", dcode(x.dtype), ptr(gy), ptr(x), ptr(gamma), ptr(mr), ptr(gx), ptr(gg), ptr(gb), rows,
-             dim, stream())
+        ws = torch.empty(1024 * 2 * dim, dtype=torch.float32, device=x.device)  # CTU_LN_BWD_MAX_BLOCKS partial rows
+        call("ctu_layernorm_bwd", dcode(x.dtype), ptr(gy), ptr(x), ptr(gamma), ptr(mr), ptr(gx), ptr(gg), ptr(gb), ptr(ws),
+             rows, dim, stream())
         return gx, gg, gb
 
 

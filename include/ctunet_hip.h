@@ -150,8 +150,12 @@ int ctu_in_bwd_apply(ctu_dtype dtype, const void* dy, const void* x, const void*
  * x,y: [rows][dim]; mean_rstd: fp32 [rows][2]; dgamma/dbeta: fp32 [dim], accumulated (atomics). */
 int ctu_layernorm_fwd(ctu_dtype dtype, const void* x, const float* gamma, const float* beta, void* y,
                       float* mean_rstd, int64_t rows, int32_t dim, ctu_stream_t stream);
+/* ws: fp32 workspace of CTU_LN_BWD_MAX_BLOCKS * 2 * dim floats (per-workgroup partial column sums; a second-stage
+ * kernel adds them into dgamma/dbeta - thousands of workgroups adding atomically into the same few hundred addresses
+ * serialise at the memory side). */
+#define CTU_LN_BWD_MAX_BLOCKS 1024
 int ctu_layernorm_bwd(ctu_dtype dtype, const void* dy, const void* x, const float* gamma, const float* mean_rstd,
-                      void* dx, float* dgamma, float* dbeta, int64_t rows, int32_t dim, ctu_stream_t stream);
+                      void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int32_t dim, ctu_stream_t stream);
 
 /* K12 GELU (exact erf) and plain adds (vit.py:37; hybrid_CTUNet.py:520; Residual :434-440). n multiple of 8. */
 int ctu_gelu_fwd(ctu_dtype dtype, const void* x, void* y, int64_t n, ctu_stream_t stream);

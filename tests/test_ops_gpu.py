@@ -58,7 +58,8 @@ def cf(t):  # NDHWC -> NCDHW
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,K,N,bias,act,res", [(300, 96, 72, True, 0, False), (257, 32, 136, True, 1, True),
                                                 (1000, 768, 64, False, 0, True), (130, 16, 16, True, 0, False),
-                                                (64, 3072, 768, True, 1, False)])
+                                                (64, 3072, 768, True, 1, False), (300, 160, 200, True, 0, False),
+                                                (2000, 256, 384, True, 0, True)])
 def test_linear(ops, dtype, M, K, N, bias, act, res):
     x, xh = dev(rnd((M, K), 1), dtype, True)
     w, wh = dev(rnd((N, K), 2, 1 / math.sqrt(K)), torch.float32, True)

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of single kernels at the shapes CTUNet d101 pf8 (B=2, bf16) actually launches.
+Usage (GPU box): python tools/kbench.py [filter]   -> prints us/launch, algorithmic TFLOP/s and GB/s per case."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hybrid_ctunet_amd  # noqa: E402,F401
+from hybrid_ctunet_amd import ops  # noqa: E402
+from hybrid_ctunet_amd._lib import Geom, call, dcode, ptr, stream  # noqa: E402
+
+DT = torch.bfloat16
+dev = "cuda"
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps  # us
+
+
+def report(name, us, flops=0.0, bytes_=0.0):
+    print(f"{name:58s} {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s  {bytes_ / us / 1e3:8.1f} GB/s", flush=True)
+
+
+def tn(M, N, K):
+    p = torch.randn(M, N, device=dev, dtype=DT)
+    q = torch.randn(M, K, device=dev, dtype=DT)
+    dw = torch.zeros(N, K, device=dev)
+    g = ops._plain_geom(M, K, N)
+    us = timeit(lambda: ops._igemm_tn(p, N, q, None, dw, g))
+    report(f"igemm_tn M={M} N={N} K={K}", us, 2.0 * M * N * K, 2.0 * M * (N + K))
+
+
+def nt(M, N, K):
+    x = torch.randn(M, K, device=dev, dtype=DT)
+    w = torch.randn(N, K, device=dev, dtype=DT)
+    out = torch.empty(M, N, device=dev, dtype=DT)
+    us = timeit(lambda: ops._plain_gemm(x, w, out, M, K, N))
+    report(f"igemm_nt M={M} N={N} K={K}", us, 2.0 * M * N * K, 2.0 * (M * (N + K) + N * K))
+
+
+def halo(B, D, H, W, C, N, what):
+    x = torch.randn(B, D, H, W, C, device=dev, dtype=DT)
+    w = torch.nn.Parameter(torch.randn(N, C, 3, 3, 3, device=dev) * 0.05)
+    flops = 2.0 * B * D * H * W * N * C * 27
+    if what == "fwd":
+        with torch.no_grad():
+            us = timeit(lambda: ops.conv3d(x, w, 1, 1))
+        report(f"conv3_halo fwd {C}->{N} @{D}x{H}x{W} B{B}", us, flops, 2.0 * B * D * H * W * (C + N))
+    else:
+        dy = torch.randn(B, D, H, W, N, device=dev, dtype=DT)
+        panel = torch.zeros(27, N, C, device=dev)
+        us = timeit(lambda: call("ctu_conv3_halo_wgrad", dcode(DT), ptr(dy), ptr(x), None, ptr(panel), B, D, H, W, C, 0, N,
+                                 stream()))
+        report(f"conv3_halo wgrad {C}->{N} @{D}x{H}x{W} B{B}", us, flops, 2.0 * B * D * H * W * (C + N))
+
+
+CASES = {
+    "tn_trunk": lambda: [tn(864, 3072, 768), tn(864, 768, 3072), tn(864, 2304, 768), tn(864, 768, 768)],
+    "tn_big": lambda: [tn(442368, 512, 128), tn(442368, 128, 512), tn(442368, 384, 128), tn(442368, 128, 32),
+                       tn(442368, 32, 128), tn(55296, 768, 256), tn(55296, 256, 64), tn(1769472, 16, 64),
+                       tn(6912, 1536, 512)],
+    "nt_trunk": lambda: [nt(864, 768, 3072), nt(864, 3072, 768), nt(864, 768, 768), nt(864, 2304, 768)],
+    "nt_big": lambda: [nt(442368, 512, 128), nt(442368, 128, 512), nt(442368, 128, 32), nt(442368, 32, 128),
+                       nt(6912, 128, 512), nt(1769472, 16, 64), nt(55296, 256, 64)],
+    "halo_fwd": lambda: [halo(2, 96, 96, 96, 64, 64, "fwd"), halo(2, 48, 48, 96, 128, 128, "fwd"),
+                         halo(2, 24, 24, 48, 256, 256, "fwd"), halo(2, 48, 48, 96, 32, 32, "fwd"),
+                         halo(2, 12, 12, 24, 512, 512, "fwd")],
+    "halo_wgrad": lambda: [halo(2, 96, 96, 96, 64, 64, "wgrad"), halo(2, 48, 48, 96, 128, 128, "wgrad"),
+                           halo(2, 24, 24, 48, 256, 256, "wgrad"), halo(2, 48, 48, 96, 32, 32, "wgrad")],
+}
+
+if __name__ == "__main__":
+    flt = sys.argv[1] if len(sys.argv) > 1 else ""
+    for k, fn in CASES.items():
+        if flt in k:
+            fn()
