@@ -53,6 +53,35 @@ def _packed(param: torch.Tensor, kind: str, dtype: torch.dtype, builder):
     return t
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# direct gradient sinks: a training harness that owns pre-zeroed, persistent fp32 gradient storage (train.FlatParams)
+# registers (parameter storage address -> callback).  Weight-gradient kernels whose output layout equals the
+# parameter layout (Linear / 1x1x1 conv weights, biases) then accumulate straight into `param.grad` and call the
+# callback, instead of materialising a zero-filled temporary that autograd adds into .grad afterwards.
+# ---------------------------------------------------------------------------------------------------------------
+_grad_sinks = {}
+
+
+def register_grad_sink(param: torch.Tensor, callback):
+    _grad_sinks[param.data_ptr()] = (weakref.ref(param), callback)
+
+
+def clear_grad_sinks():
+    _grad_sinks.clear()
+
+
+def _direct_grad(param):
+    """param.grad if a sink is registered for this parameter and its .grad can be accumulated into in place."""
+    ent = _grad_sinks.get(param.data_ptr()) if param is not None else None
+    if ent is None:
+        return None, None
+    p = ent[0]()
+    if p is None or p.grad is None or p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or \
+            p.grad.shape != param.shape:
+        return None, None
+    return p.grad, lambda: ent[1](p)
+
+
 def permute3(src: torch.Tensor, dst: torch.Tensor, n, s, d, accumulate=False):
     """dst[i0*d0+i1*d1+i2*d2] (+)= src[i0*s0+i1*s1+i2*s2]; src fp32."""
     assert src.dtype == torch.float32
@@ -150,7 +179,7 @@ class LinearFn(torch.autograd.Function):
                 call("ctu_add", dcode(x.dtype), ptr(out), ptr(residual), ptr(out), out.numel(), stream())
         else:
             _plain_gemm(x, wf, out, M, K, N, bias=bias, residual=residual, act=act)
-        ctx.save_for_backward(x, weight, pre)
+        ctx.save_for_backward(x, weight, pre, bias)
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         ctx.act = act
@@ -158,7 +187,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, pre = ctx.saved_tensors
+        x, weight, pre, bias = ctx.saved_tensors
         gy = gy.contiguous()
         N, K = weight.shape[0], weight[0].numel()
         M = x.numel() // K
@@ -173,13 +202,21 @@ class LinearFn(torch.autograd.Function):
             gx = torch.empty_like(x)
             _plain_gemm(g, wd, gx, M, N, K)
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
-        if want_gb:
-            gb = torch.zeros(N, dtype=torch.float32, device=x.device)
+        # accumulate straight into persistent .grad storage when the harness registered it (see register_grad_sink)
+        gw_buf, gw_done = _direct_grad(weight) if ctx.needs_input_grad[1] else (None, None)
+        gb_buf, gb_done = _direct_grad(bias) if want_gb else (None, None)
+        if want_gb and gb_buf is None:
+            gb = gb_buf = torch.zeros(N, dtype=torch.float32, device=x.device)
         if ctx.needs_input_grad[1]:
-            gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
-            _igemm_tn(g, N, x, None, gw, _plain_geom(M, K, N), bias_grad=gb if want_gb else None)  # bias grad rides along
+            if gw_buf is None:
+                gw = gw_buf = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+            _igemm_tn(g, N, x, None, gw_buf, _plain_geom(M, K, N), bias_grad=gb_buf if want_gb else None)
         elif want_gb:
-            call("ctu_colsum", dcode(g.dtype), ptr(g), M, N, N, ptr(gb), stream())
+            call("ctu_colsum", dcode(g.dtype), ptr(g), M, N, N, ptr(gb_buf), stream())
+        if gw_done is not None:
+            gw_done()
+        if gb_done is not None:
+            gb_done()
         return gx, gw, gb, gres, None
 
 
@@ -436,21 +473,29 @@ class LayerNormFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mr = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
         call("ctu_layernorm_fwd", dcode(x.dtype), ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mr), rows, dim, stream())
-        ctx.save_for_backward(x, gamma, mr)
+        ctx.save_for_backward(x, gamma, mr, beta)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, gamma, mr = ctx.saved_tensors
+        x, gamma, mr, beta = ctx.saved_tensors
         gy = gy.contiguous()
         dim = x.shape[-1]
         rows = x.numel() // dim
         gx = torch.empty_like(x)
-        gg = torch.zeros(dim, dtype=torch.float32, device=x.device)
-        gb = torch.zeros(dim, dtype=torch.float32, device=x.device)
+        gg_buf, gg_done = _direct_grad(gamma)
+        gb_buf, gb_done = _direct_grad(beta)
+        gg = gb = None
+        if gg_buf is None or gb_buf is None:
+            gg_buf = gg = torch.zeros(dim, dtype=torch.float32, device=x.device)
+            gb_buf = gb = torch.zeros(dim, dtype=torch.float32, device=x.device)
+            gg_done = gb_done = None
         ws = torch.empty(1024 * 2 * dim, dtype=torch.float32, device=x.device)  # CTU_LN_BWD_MAX_BLOCKS partial rows
-        call("ctu_layernorm_bwd", dcode(x.dtype), ptr(gy), ptr(x), ptr(gamma), ptr(mr), ptr(gx), ptr(gg), ptr(gb), ptr(ws),
-             rows, dim, stream())
+        call("ctu_layernorm_bwd", dcode(x.dtype), ptr(gy), ptr(x), ptr(gamma), ptr(mr), ptr(gx), ptr(gg_buf), ptr(gb_buf),
+             ptr(ws), rows, dim, stream())
+        if gg_done is not None:
+            gg_done()
+            gb_done()
         return gx, gg, gb
 
 

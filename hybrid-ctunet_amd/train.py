@@ -155,12 +155,24 @@ class FlatParams:
                 p.data = self.flat[o:o + p.numel()].view(p.shape)
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
         self.touched = [False] * len(self.params)
+        self.listeners = []  # callables(i): "the gradient of parameter i is complete for this backward"
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+        if self.flat.is_cuda:
+            # let weight-gradient kernels accumulate straight into the flat buffer (no zero-filled temporaries, no adds)
+            for i, p in enumerate(self.params):
+                ops.register_grad_sink(p, self._make_sink(i))
         ops.bump_weights_epoch()
+
+    def _ready(self, i):
+        self.touched[i] = True
+        for fn in self.listeners:
+            fn(i)
+
+    def _make_sink(self, i):
+        return lambda p: self._ready(i)
 
     def _make_hook(self, i):
         def hook(p):
-            self.touched[i] = True
             # autograd may have replaced .grad (first accumulation into a None grad): fold it back into the flat buffer
             g = p.grad
             o = self.offsets[i]
@@ -168,6 +180,7 @@ class FlatParams:
             if g is not None and g.data_ptr() != view.data_ptr():
                 view.add_(g)
                 p.grad = view
+            self._ready(i)
         return hook
 
     def zero_grad(self):
@@ -269,7 +282,8 @@ class DataParallel(nn.Module):
         self._works = []
         self._is_cuda = f.flat.is_cuda
         self._side = torch.cuda.Stream() if self._is_cuda else None
-        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(f.params)]
+        self._seen = [False] * len(f.params)
+        f.listeners.append(self._on_ready)  # fires for autograd-accumulated and for directly accumulated gradients
         if broadcast and self.world > 1:
             dist.broadcast(f.flat, src=0, group=self.pg)  # DDP ctor semantics: rank 0's parameters win
             ops.bump_weights_epoch()
@@ -277,13 +291,14 @@ class DataParallel(nn.Module):
     def forward(self, *a, **kw):
         return self.module(*a, **kw)
 
-    def _make_hook(self, i):
-        def hook(p):
-            b = self._bucket_of[i]
-            self._pending[b] -= 1
-            if self._pending[b] == 0:
-                self._launch(b)
-        return hook
+    def _on_ready(self, i):
+        if self._seen[i]:  # a parameter used twice in one graph reports twice; count it once
+            return
+        self._seen[i] = True
+        b = self._bucket_of[i]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
 
     def _launch(self, b):
         if self._launched[b] or self.world == 1:
@@ -315,6 +330,7 @@ class DataParallel(nn.Module):
             torch.cuda.current_stream().wait_stream(self._side)
         self._pending = [len(mem) for _, _, mem in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._seen = [False] * len(self.flat.params)
 
 
 def gradient_ready_order(model: nn.Module) -> List[nn.Parameter]:

@@ -366,6 +366,37 @@ def test_dice_ce(ops, dtype, shape, tshape, weight):
     close(plain.grad, held.grad / 1.5, dtype, "dlogits-plain")
 
 
+def test_direct_gradient_sink_matches_autograd_path(ops):
+    """With train.FlatParams the Linear/LayerNorm weight-gradient kernels accumulate straight into the flat buffer
+    (ops.register_grad_sink); the result must equal the ordinary autograd path, accumulate over repeated backwards,
+    and mark the parameters as touched."""
+    from hybrid_ctunet_amd.train import FlatParams
+    torch.manual_seed(0)
+    dim, hid = 64, 160
+    params = dict(w1=torch.randn(hid, dim) * 0.1, b1=torch.randn(hid) * 0.1, w2=torch.randn(dim, hid) * 0.1,
+                  g=1 + 0.1 * torch.randn(dim), be=0.1 * torch.randn(dim), unused=torch.randn(5))
+    x = torch.randn(300, dim)
+    gy = torch.randn(300, dim)
+
+    def run(ps, xx):
+        h = ops.layer_norm(xx, ps["g"], ps["be"])
+        h = ops.linear(h, ps["w1"], ps["b1"], None, 1)
+        return ops.linear(h, ps["w2"], None, xx, 0)
+
+    ref = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in params.items()}
+    for _ in range(2):
+        run(ref, x.cuda()).backward(gy.cuda())
+    direct = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in params.items()}
+    fp = FlatParams(direct.values())
+    for _ in range(2):
+        run(direct, x.cuda()).backward(gy.cuda())
+    for k in ("w1", "b1", "w2", "g", "be"):
+        close(direct[k].grad, ref[k].grad.cpu().double(), torch.float32, k)
+        assert direct[k].grad.data_ptr() >= fp.grad.data_ptr()
+    assert fp.touched == [True, True, True, True, True, False]
+    ops.clear_grad_sinks()
+
+
 def test_fused_adamw_matches_torch(ops):
     from hybrid_ctunet_amd.train import FusedAdamW
     torch.manual_seed(0)
