@@ -158,8 +158,248 @@ __global__ __launch_bounds__(256) void conv3_halo_kernel(const HaloArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16 production variant: every operand reaches LDS by LDS-DMA (global_load_lds_dwordx4), nothing is staged
+// through registers and no wave waits on a global load it issued itself in the same stage.
+//   * halo: 16-channel half chunks (600 voxels x 32 B), double buffered; the next half chunk is in flight while
+//     the 27 taps of the current one are computed.  The LDS image is lane-linear (DMA rule), so the bank swizzle
+//     sits on the SOURCE address: 16-B slot of (voxel v, k-half hs) = 2 v + (hs ^ ((row(v) >> 1) & 1)), and the
+//     32 rows of an M tile are dealt to voxels so that each 16-lane ds_read_b128 group covers two halo rows two
+//     apart -> all 16 slots of the 256-B bank row, conflict free for every tap.
+//   * weights: the 1 KiB MFMA-order fragments of 3 taps form a stage, fetched ONCE per workgroup into a 3-stage
+//     ring (the register-streaming kernel above fetched them once per wave: 64 B/clk/CU of L1 traffic at full
+//     MFMA rate).  One raw s_barrier per stage (6 NT MFMAs per wave); counted vmcnt keeps two stages plus the
+//     halo prefetch in flight across it.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) uint32_t g_zero16[4];  // source of out-of-volume halo slots
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+// 64 lanes x 16 B: lane l's 16 bytes at gsrc land at LDS byte address lds_wave_base + 16 l.  Written in assembly so
+// that hipcc does not count it: with the builtin it drains vmcnt(0) in front of the next LDS read that might alias,
+// which serialises exactly the overlap these kernels are built around.  Completion is OUR job: counted
+// s_waitcnt vmcnt(N), then a barrier, then the ds_read.  M0 is compiler-reserved, so it is saved and restored.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_base) {
+  const unsigned dst =
+      __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vm_then_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_vm_then_barrier_n(int n) {  // n is wave-uniform
+  switch (n) {
+    case 1: wait_vm_then_barrier<1>(); break;
+    case 2: wait_vm_then_barrier<2>(); break;
+    case 3: wait_vm_then_barrier<3>(); break;
+    case 4: wait_vm_then_barrier<4>(); break;
+    case 5: wait_vm_then_barrier<5>(); break;
+    case 6: wait_vm_then_barrier<6>(); break;
+    case 7: wait_vm_then_barrier<7>(); break;
+    case 8: wait_vm_then_barrier<8>(); break;
+    default: wait_vm_then_barrier<0>(); break;
+  }
+}
+
+// row of a 32-row M tile -> (h, w) inside the tile's 4 x 8 voxel patch (see the bank argument above)
+__device__ __forceinline__ void halo_row_to_hw(int row, int& hh, int& ww) {
+  const int q = row >> 2;
+  hh = 2 * (q >> 2) + ((q ^ (q >> 1) ^ (q >> 2)) & 1);
+  ww = 4 * ((q >> 1) & 1) + (row & 3);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv3_halo_dma_kernel(const HaloArgs p) {
+  constexpr int HINS = 19;            // DMA wave-instructions per halo half chunk (1216 slots >= 600 voxels x 2)
+  constexpr int HBUF = HINS * 1024;
+  constexpr int SFR = 3 * NT;         // weight fragments (1 KiB each) per stage of 3 taps
+  constexpr int SBYTES = SFR * 1024;
+  constexpr int RING0 = 2 * HBUF;
+  constexpr int STAGE_LD = 32 + 4;
+  constexpr int LDS_MAIN = RING0 + 3 * SBYTES;
+  constexpr int LDS_EPI = 4 * 32 * STAGE_LD * 4;
+  constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int bw = t % p.nbw; t /= p.nbw;
+  const int bh = t % p.nbh; t /= p.nbh;
+  const int bd = t % p.nbd;
+  const int b = t / p.nbd;
+  const int d0 = bd * HB_D, h0 = bh * HB_H, w0 = bw * HB_W;
+  const int nt0 = blockIdx.y * NT;
+  const int HC = (p.C1 + p.C2) / 16;  // half chunks
+  const int U = HC * 9;               // stages
+  const bf16* x1 = reinterpret_cast<const bf16*>(p.x1);
+  const bf16* x2 = reinterpret_cast<const bf16*>(p.x2);
+  const bf16* wf = reinterpret_cast<const bf16*>(p.wfrag);
+
+  // ---- per-lane halo sources of this wave's DMA instructions (instruction i = wave + 4k fills slots 64 i ..) ----
+  int hm[5];
+  unsigned hpart = 0;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int S = (wave + 4 * k) * 64 + lane;
+    int m = -1;
+    if (S < 2 * HALO_VOX) {
+      const int vox = S >> 1, hs = S & 1;
+      const int R = vox / HALO_W, hw = vox - R * HALO_W;
+      const int hd = R / HALO_H, hh = R - hd * HALO_H;
+      const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+      hpart |= (unsigned)(hs ^ ((R >> 1) & 1)) << k;
+      if ((unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W)
+        m = ((b * p.D + gd) * p.H + gh) * p.W + gw;
+    }
+    hm[k] = m;
+  }
+  const int h_w = (HINS - wave + 3) >> 2;  // DMA instructions of this wave per halo half chunk / per weight stage
+  const int b_w = (SFR - wave + 3) >> 2;
+
+  auto issue_halo = [&](int hc) {
+    const int c0 = hc * 16;
+    const bool first = c0 < p.C1;
+    const bf16* src = first ? x1 : x2;
+    const int cs = first ? p.C1 : p.C2;
+    const int cc = first ? c0 : c0 - p.C1;
+    unsigned char* dst = smem + (hc & 1) * HBUF;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int i = wave + 4 * k;
+      if (i < HINS) {
+        const bf16* g = hm[k] >= 0 ? src + (size_t)hm[k] * cs + cc + ((hpart >> k) & 1) * 8
+                                   : reinterpret_cast<const bf16*>(g_zero16);
+        dma16(g, dst + i * 1024);
+      }
+    }
+  };
+  auto issue_b = [&](int hc, int s, int slot) {
+    const bf16* base = wf + ((size_t)(((hc >> 1) * 27 + 3 * s) * 2 + (hc & 1)) * p.ntn + nt0) * 512 + lane * 8;
+    unsigned char* dst = smem + RING0 + slot * SBYTES;
+#pragma unroll
+    for (int k = 0; k < (SFR + 3) / 4; ++k) {
+      const int f = wave + 4 * k;
+      if (f < SFR) {
+        const int tapi = f / NT, j = f - tapi * NT;
+        dma16(base + (size_t)(tapi * 2 * p.ntn + j) * 512, dst + f * 1024);
+      }
+    }
+  };
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  int vrow, vcol;
+  halo_row_to_hw(r, vrow, vcol);
+
+  issue_halo(0);
+  issue_b(0, 0, 0);
+  issue_b(0, 1, 1);
+  int hc = 0, s = 0, rs = 0;     // stage being computed: half chunk, (td, th) index, ring slot
+  int ihc = 0, is = 2, irs = 2;  // stage being fetched (two ahead)
+  for (int u = 0; u < U; ++u) {
+    // own DMAs of this stage (and, being older, of its halo) have landed; still in flight: the next stage and a
+    // halo prefetch issued in one of the last two stages
+    const bool halo_in_flight = (s == 1 || s == 2) && hc + 1 < HC;
+    wait_vm_then_barrier_n(b_w + (halo_in_flight ? h_w : 0));
+    issue_b(ihc, is, irs);  // past the end: refetches the last stage into a slot nobody reads (keeps the counts)
+    if (u + 3 < U) {
+      if (++is == 9) { is = 0; ++ihc; }
+    }
+    irs = irs == 2 ? 0 : irs + 1;
+    if (s == 0 && hc + 1 < HC) issue_halo(hc + 1);
+
+    const int td = (s * 11) >> 5, th = s - 3 * td;
+    const unsigned char* hb = smem + (hc & 1) * HBUF;
+    const unsigned char* rb = smem + RING0 + rs * SBYTES + lane * 16;
+    int aoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int R = (wave + td) * HALO_H + 4 * i + vrow + th;
+      aoff[i] = ((R * HALO_W + vcol) * 2 + (h ^ ((R >> 1) & 1))) * 16;
+    }
+#pragma unroll
+    for (int tw = 0; tw < 3; ++tw) {
+      bf16x8 fa[2], fb[NT];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(hb + aoff[i] + tw * 32);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(rb + (tw * NT + j) * 1024);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (++s == 9) { s = 0; ++hc; }
+    rs = rs == 2 ? 0 : rs + 1;
+  }
+  wait_vm_then_barrier<0>();  // the tail refetches have landed; LDS is free for the epilogue
+
+  float* stage = reinterpret_cast<float*>(smem) + wave * 32 * STAGE_LD;
+  bf16* out = reinterpret_cast<bf16*>(p.out);
+  bf16* out2 = reinterpret_cast<bf16*>(p.out2);
+  const int gd = d0 + wave;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) stage[((e & 3) + 8 * (e >> 2) + 4 * h) * STAGE_LD + r] = acc[i][j][e];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int vv = lane + 64 * q;  // 128 vectors: 32 rows x 4 groups of 8 channels
+        const int row = vv >> 2, cv = vv & 3;
+        int hh, ww;
+        halo_row_to_hw(row, hh, ww);
+        const int gh = h0 + 4 * i + hh, gw = w0 + ww;
+        const int n = (nt0 + j) * 32 + cv * 8;
+        if (gd < p.D && gh < p.H && gw < p.W && n < p.N) {
+          float xv[8];
+          load8(&stage[row * STAGE_LD + cv * 8], xv);
+          const size_t m = (((size_t)b * p.D + gd) * p.H + gh) * p.W + gw;
+          if (p.n_split > 0 && n >= p.n_split) store8(out2 + m * p.ldc2 + (n - p.n_split), xv);
+          else store8(out + m * p.ldc + n, xv);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename T> struct HaloDma {
+  static bool launch(const HaloArgs&, hipStream_t) { return false; }
+};
+template <> struct HaloDma<bf16> {
+  static bool launch(const HaloArgs& p, hipStream_t s) {
+    // 32-bit voxel indices and element offsets inside the kernel
+    const int64_t vox = (int64_t)p.B * p.D * p.H * p.W;
+    const int cmax = p.C1 > p.C2 ? p.C1 : p.C2;
+    if (vox * cmax >= (1ll << 31)) return false;
+    const int bricks = p.B * p.nbd * p.nbh * p.nbw;
+    const int ntn = p.ntn;
+    if (ntn % 4 == 0) hipLaunchKernelGGL(conv3_halo_dma_kernel<4>, dim3(bricks, ntn / 4), dim3(256), 0, s, p);
+    else if (ntn % 2 == 0) hipLaunchKernelGGL(conv3_halo_dma_kernel<2>, dim3(bricks, ntn / 2), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv3_halo_dma_kernel<1>, dim3(bricks, ntn), dim3(256), 0, s, p);
+    return true;
+  }
+};
+
 template <typename T>
 static int launch_halo(const HaloArgs& p, hipStream_t s) {
+  if (HaloDma<T>::launch(p, s)) return ctu_check_launch("conv3_halo");
   const int ntn = p.ntn;
   const int bricks = p.B * p.nbd * p.nbh * p.nbw;
   if (ntn >= 4 && ntn % 4 == 0)
@@ -201,7 +441,7 @@ struct HaloWgArgs {
   const void* x2;
   float* dw;  // [27][N][K]
   int B, D, H, W, C1, C2, N;
-  int nbd, nbh, nbw, nbricks, bricks_per_block, tiles_c;
+  int nbd, nbh, nbw, nbricks, bricks_per_block, tiles_c, tiles_n;
 };
 
 template <typename T>
@@ -293,6 +533,138 @@ __global__ __launch_bounds__(256) void conv3_halo_wgrad_kernel(const HaloWgArgs 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16 production variant of the weight gradient: LDS-DMA staging, double buffered over bricks.
+// One workgroup of 8 waves per CU owns (32 NTN output channels) x (32 input channels) for all 27 taps; wave w holds
+// n tile w & 1 and taps (w >> 1) + 4 i (NTN = 2), or taps w + 8 i (NTN = 1).  While the MFMAs of brick k run, the halo
+// chunk and dY tile of brick k+1 are in flight into the other buffer: one barrier per brick, no register staging.
+// Both LDS images are plain [voxel][32 channels] (64-B rows, lane-linear as LDS-DMA requires): a transposed
+// ds_read_b64_tr_b16 touches 4 consecutive voxels x 64 B = one whole 256-B bank row, conflict free without padding.
+// Workgroups that walk the same brick range (all tiles of one split) are placed on one XCD so that the halo / dY
+// bytes they share are served by that XCD's L2.
+// ---------------------------------------------------------------------------------------------------------
+template <int NTN>
+__global__ __launch_bounds__(512, 1) void conv3_halo_wgrad_dma_kernel(const HaloWgArgs p) {
+  constexpr int HINS = 38;              // DMA wave-instructions per halo chunk: 600 voxels x 4 slots = 2400 <= 2432
+  constexpr int HBYTES = HINS * 1024;
+  constexpr int YBYTES = 256 * 64;      // dY tile of one 32-wide n tile
+  constexpr int BUF = HBYTES + NTN * YBYTES;
+  constexpr int NI = NTN == 2 ? 7 : 4;  // accumulator tiles per wave
+  constexpr int TS = NTN == 2 ? 4 : 8;  // tap stride between them
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = NTN == 2 ? (wave & 1) : 0;
+  const int t0 = NTN == 2 ? (wave >> 1) : wave;
+  const int vid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = p.tiles_n * p.tiles_c;
+  const int tile = vid % tiles, split = vid / tiles;
+  const int n0 = (tile / p.tiles_c) * 32 * NTN;
+  const int c0 = (tile % p.tiles_c) * 32;
+  const int K = p.C1 + p.C2;
+  const bool first = c0 < p.C1;
+  const bf16* src = first ? reinterpret_cast<const bf16*>(p.x1) : reinterpret_cast<const bf16*>(p.x2);
+  const int cs = first ? p.C1 : p.C2;
+  const int cc = first ? c0 : c0 - p.C1;
+  const bf16* dy = reinterpret_cast<const bf16*>(p.dy);
+  const bf16* zero = reinterpret_cast<const bf16*>(g_zero16);
+
+  // brick-independent part of this lane's DMA sources: halo voxel (hd, hh, hw) and 8-channel part per instruction
+  int hv[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int S = (wave + 8 * k) * 64 + lane;
+    const int vox = S >> 2;
+    const int R = vox / HALO_W, hw = vox - R * HALO_W;
+    const int hd = R / HALO_H, hh = R - hd * HALO_H;
+    hv[k] = S < 4 * HALO_VOX ? (hd | (hh << 4) | (hw << 8) | ((S & 3) << 12)) : -1;
+  }
+
+  auto issue = [&](int brick, int buf) {
+    int t = brick;
+    const int bw = t % p.nbw; t /= p.nbw;
+    const int bh = t % p.nbh; t /= p.nbh;
+    const int bd = t % p.nbd;
+    const int b = t / p.nbd;
+    const int d0 = bd * HB_D, h0 = bh * HB_H, w0 = bw * HB_W;
+    unsigned char* dst = smem + buf * BUF;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int i = wave + 8 * k;
+      if (i < HINS) {
+        const int gd = d0 + (hv[k] & 15) - 1, gh = h0 + ((hv[k] >> 4) & 15) - 1, gw = w0 + ((hv[k] >> 8) & 15) - 1;
+        const bool ok = hv[k] >= 0 && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
+                        (unsigned)gw < (unsigned)p.W;
+        const int m = ((b * p.D + gd) * p.H + gh) * p.W + gw;
+        dma16(ok ? src + (size_t)m * cs + cc + ((hv[k] >> 12) & 3) * 8 : zero, dst + i * 1024);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * NTN; ++k) {
+      const int j = wave + 8 * k;  // < 16 NTN
+      const int S = (j & 15) * 64 + lane;
+      const int vox = S >> 2;
+      const int gd = d0 + (vox >> 6), gh = h0 + ((vox >> 3) & 7), gw = w0 + (vox & 7);
+      const int n = n0 + (j >> 4) * 32 + (S & 3) * 8;
+      const bool ok = gd < p.D && gh < p.H && gw < p.W && n < p.N;
+      const int m = ((b * p.D + gd) * p.H + gh) * p.W + gw;
+      dma16(ok ? dy + (size_t)m * p.N + n : zero, dst + HBYTES + j * 1024);
+    }
+  };
+
+  f32x16 acc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  // halo element offset of each owned tap (+ this lane's channel); a wave with one tap fewer repeats tap 26 into an
+  // accumulator that is never written back - it would only wait at the brick barrier otherwise, and the k loop stays
+  // free of branches
+  int tapoff[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int tap = min(t0 + TS * i, 26);
+    const int tw = tap % 3, tq = tap / 3;
+    const int th = tq % 3, td = tq / 3;
+    tapoff[i] = ((td * HALO_H + th) * HALO_W + tw) * 32 + r;
+  }
+
+  const int brick_begin = split * p.bricks_per_block;
+  const int brick_end = min(p.nbricks, brick_begin + p.bricks_per_block);
+  if (brick_begin < brick_end) issue(brick_begin, 0);
+  int buf = 0;
+  for (int brick = brick_begin; brick < brick_end; ++brick, buf ^= 1) {
+    // this brick's DMAs (issued one compute phase ago) have landed in every wave, and every wave is done reading
+    // the other buffer
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (brick + 1 < brick_end) issue(brick + 1, buf ^ 1);
+    const bf16* halo = reinterpret_cast<const bf16*>(smem + buf * BUF);
+    const bf16* dyt = reinterpret_cast<const bf16*>(smem + buf * BUF + HBYTES + nt * YBYTES);
+#pragma unroll 2
+    for (int s = 0; s < 16; ++s) {
+      const int d = s >> 2, hh = 2 * (s & 3) + h;  // this lane half's row of 8 voxels along w
+      const bf16x8 fa = Mma<bf16>::gather(&dyt[(d * 64 + hh * 8) * 32 + r], 32);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        Mma<bf16>::mma(fa, Mma<bf16>::gather(&halo[tapoff[i] + ((d * HALO_H + hh) * HALO_W) * 32], 32), acc[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int tap = t0 + TS * i;
+    if (tap < 27) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int c = c0 + r;
+        if (n < p.N && c < K) atomicAdd(&p.dw[((size_t)tap * p.N + n) * K + c], acc[i][e]);
+      }
+    }
+  }
+}
+
 extern "C" int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void* x1, const void* x2, float* dw, int32_t B,
                                     int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N,
                                     ctu_stream_t stream) {
@@ -308,7 +680,24 @@ extern "C" int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void*
   CTU_REQUIRE(nbricks < (1ll << 31), "conv3_halo_wgrad: too many bricks");
   p.nbricks = (int)nbricks;
   p.tiles_c = (C1 + C2) / 32;
-  const int tiles = ((N + 31) / 32) * p.tiles_c;
+  hipStream_t s = (hipStream_t)stream;
+  const int cmax = (C1 > C2 ? C1 : C2) > N ? (C1 > C2 ? C1 : C2) : N;
+  if (dtype == CTU_BF16 && nbricks * 256 * cmax < (1ll << 31)) {
+    // LDS-DMA kernel: one resident workgroup per CU (256 CUs), 32-bit element offsets
+    const int ntn = N > 32 ? 2 : 1;
+    p.tiles_n = (N + 32 * ntn - 1) / (32 * ntn);
+    const int tiles = p.tiles_n * p.tiles_c;
+    int splits = (256 + tiles - 1) / tiles;
+    if (splits > p.nbricks) splits = p.nbricks;
+    p.bricks_per_block = (p.nbricks + splits - 1) / splits;
+    splits = (p.nbricks + p.bricks_per_block - 1) / p.bricks_per_block;
+    CTU_REQUIRE((int64_t)tiles * splits < (1ll << 31), "conv3_halo_wgrad: too many workgroups");
+    if (ntn == 2) hipLaunchKernelGGL(conv3_halo_wgrad_dma_kernel<2>, dim3(tiles * splits), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL(conv3_halo_wgrad_dma_kernel<1>, dim3(tiles * splits), dim3(512), 0, s, p);
+    return ctu_check_launch("conv3_halo_wgrad");
+  }
+  p.tiles_n = (N + 31) / 32;
+  const int tiles = p.tiles_n * p.tiles_c;
   int splits = (512 + tiles - 1) / tiles;  // ~2 resident workgroups per CU
   if (splits > p.nbricks) splits = p.nbricks;
   if (splits < 1) splits = 1;
@@ -316,7 +705,6 @@ extern "C" int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void*
   splits = (p.nbricks + p.bricks_per_block - 1) / p.bricks_per_block;
   CTU_REQUIRE(splits <= 65535, "conv3_halo_wgrad: too many splits");
   dim3 grid(tiles, splits);
-  hipStream_t s = (hipStream_t)stream;
   CTU_DISPATCH(dtype, hipLaunchKernelGGL(conv3_halo_wgrad_kernel<float>, grid, dim3(256), 0, s, p),
                hipLaunchKernelGGL(conv3_halo_wgrad_kernel<bf16>, grid, dim3(256), 0, s, p));
   return ctu_check_launch("conv3_halo_wgrad");

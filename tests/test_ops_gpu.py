@@ -102,6 +102,7 @@ CONV_CASES = [  # B, D,H,W, C1, C2, N, k, s, p
     (2, 7, 9, 17, 32, 32, 64, 3, 1, 1),   # halo kernel: concat forward + split data gradient, ragged bricks
     (1, 12, 12, 24, 96, 0, 32, 3, 1, 1),  # halo kernel: NT=1, three chunks
     (1, 5, 16, 8, 64, 64, 160, 3, 1, 1),  # halo kernel: N=160 -> 5 n tiles (NT=1 path), concat
+    (1, 8, 8, 16, 256, 0, 256, 3, 1, 1),  # halo kernel: 8 n tiles -> two n blocks, 16 half chunks, several bricks/workgroup
 ]
 
 
