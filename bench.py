@@ -46,10 +46,12 @@ class KernelTimer:
         if name == "ctu_conv3_halo":       # (dtype, x1, x2, w, out, out2, B, D, H, W, C1, C2, N, ...)
             B, D, H, W, C1, C2, N = args[6:13]
             self.rec.append((name, 2.0 * B * D * H * W * N * (C1 + C2) * 27, e0, e1))
+            self.shape[len(self.rec) - 1] = f"conv3_halo {C1}+{C2}->{N} @{D}x{H}x{W} B{B}"
             return
         if name == "ctu_conv3_halo_wgrad":  # (dtype, dy, x1, x2, dw, B, D, H, W, C1, C2, N, stream)
             B, D, H, W, C1, C2, N = args[5:12]
             self.rec.append((name, 2.0 * B * D * H * W * N * (C1 + C2) * 27, e0, e1))
+            self.shape[len(self.rec) - 1] = f"conv3_halo_wgrad {C1}+{C2}->{N} @{D}x{H}x{W} B{B}"
             return
         g = args[5] if name == "ctu_igemm_nt" else args[7]  # (dtype, p, ldp, q1, q2, dw, bias_grad, geom, stream)
         taps = g.kd * g.kh * g.kw
@@ -191,7 +193,7 @@ def main():
         _lib.PROFILER = None
         s = timer.summary()
         if os.environ.get("CTU_BENCH_SHAPES"):
-            print("\n".join(timer.by_shape()), file=sys.stderr, flush=True)
+            print("\n".join(timer.by_shape(int(os.environ["CTU_BENCH_SHAPES"]) if os.environ["CTU_BENCH_SHAPES"].isdigit() and int(os.environ["CTU_BENCH_SHAPES"]) > 1 else 25)), file=sys.stderr, flush=True)
         dom = max(s, key=lambda k: s[k]["ms"])
         tot = {k: round(v["ms"] / 2, 3) for k, v in s.items()}
         ach = s[dom]["flops"] / (s[dom]["ms"] * 1e-3) / 1e12
