@@ -13,8 +13,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libctunet_hip.so")
-SOURCES = ["igemm.hip", "conv3_halo.hip", "norm_elementwise.hip", "attention.hip", "attention_mfma.hip",
-           "loss_optim.hip", "mma.h", "attn_common.h"]
+SOURCES = ["igemm.hip", "gemm_dma.hip", "conv3_halo.hip", "norm_elementwise.hip", "attention.hip", "attention_mfma.hip",
+           "loss_optim.hip", "mma.h", "dma.h", "gemm_dma.h", "attn_common.h", "common.h"]
 
 CTU_F32, CTU_BF16 = 0, 1
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -43,7 +43,7 @@ class AttnGeom(C.Structure):
 # name -> argtypes (all return int status except the two noted)
 _SIGS = {
     "ctu_igemm_nt": [_i32, _vp, _vp, _vp, _vp, C.POINTER(Geom), C.POINTER(Epilogue), _vp],
-    "ctu_igemm_tn": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, C.POINTER(Geom), _vp],
+    "ctu_igemm_tn": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, C.POINTER(Geom), _vp, _i64, _vp],
     "ctu_conv3_halo": [_i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 10 + [_vp],
     "ctu_conv3_halo_wgrad": [_i32, _vp, _vp, _vp, _vp] + [_i32] * 7 + [_vp],
     "ctu_pack_frag": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp],
@@ -54,7 +54,7 @@ _SIGS = {
     "ctu_in_stats": [_i32, _vp, _i32, _i64, _i32, _vp, _vp, _vp],
     "ctu_in_apply": [_i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp],
     "ctu_in_bwd_reduce": [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp],
-    "ctu_in_bwd_apply": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp],
+    "ctu_in_bwd_apply": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i32, _vp],
     "ctu_layernorm_fwd": [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "ctu_layernorm_bwd": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "ctu_gelu_fwd": [_i32, _vp, _vp, _i64, _vp],
@@ -110,7 +110,7 @@ def lib():
             fn.restype = C.c_int
         L.ctu_abi_version.restype = C.c_int
         L.ctu_last_error.restype = C.c_char_p
-        if L.ctu_abi_version() != 1:
+        if L.ctu_abi_version() != 2:
             raise RuntimeError("libctunet_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -16,6 +16,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 void ctu_set_error(const char* fmt, ...);
 int ctu_check_launch(const char* what);
+int ctu_option_generic_gemm();  // test hook, see ctu_set_option
 
 #define CTU_REQUIRE(cond, ...)      \
   do {                              \

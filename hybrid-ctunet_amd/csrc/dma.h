@@ -1,0 +1,40 @@
+// LDS-DMA (global_load_lds_dwordx4) helpers shared by the kernels that stage operands without registers (gfx950).
+#pragma once
+#include "common.h"
+
+static __device__ __attribute__((aligned(16))) uint32_t g_zero16[4];  // 16 zero bytes: DMA source of padding slots
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+// 64 lanes x 16 B: lane l's 16 bytes at gsrc land at LDS byte address lds_wave_base + 16 l.  Written in assembly so
+// that hipcc does not count it: with the builtin it drains vmcnt(0) in front of the next LDS read that might alias,
+// which serialises exactly the overlap these kernels are built around.  Completion is OUR job: counted
+// s_waitcnt vmcnt(N), then a barrier, then the ds_read.  M0 is compiler-reserved, so it is saved and restored.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_base) {
+  const unsigned dst =
+      __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vm_then_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_vm_then_barrier_n(int n) {  // n is wave-uniform
+  switch (n) {
+    case 1: wait_vm_then_barrier<1>(); break;
+    case 2: wait_vm_then_barrier<2>(); break;
+    case 3: wait_vm_then_barrier<3>(); break;
+    case 4: wait_vm_then_barrier<4>(); break;
+    case 5: wait_vm_then_barrier<5>(); break;
+    case 6: wait_vm_then_barrier<6>(); break;
+    case 7: wait_vm_then_barrier<7>(); break;
+    case 8: wait_vm_then_barrier<8>(); break;
+    default: wait_vm_then_barrier<0>(); break;
+  }
+}
+

@@ -1,0 +1,426 @@
+// Plain bf16 GEMMs (no gather: 1x1x1 stride-1 convolutions, nn.Linear, transposed-conv panels) with LDS-DMA staging.
+//
+//   gemm_nt_dma : out[m][n] = sum_k A[m][k] W[n][k]  (+ the ctu_epilogue: bias / GELU / residual / split / scatter)
+//   gemm_tn_dma : dw[n][c] += sum_m P[m][n] Q[m][c]  (weight gradients of the same layers)
+//
+// The generic implicit-GEMM kernels (igemm.hip) stage 32-deep k slices through registers with one barrier per
+// 8 MFMAs and a fresh workgroup per output tile; at this model's shapes (K = 32..3072, M = 864 or 10^5..10^6) they reach
+// ~2.2 TB/s on the HBM-bound layers and ~90 TFLOP/s on the 864-token ViT trunk.  Here:
+//   * operands go global -> LDS by DMA (no VGPR staging), 64-deep stages, two stages per workgroup and two
+//     workgroups per CU (64 KiB in flight per CU);
+//   * workgroups are persistent: the DMA of the NEXT tile's first stage is issued before the epilogue of the
+//     current tile, so short-K tiles (K = 128 is two stages) do not expose a load latency per tile;
+//   * 128-B LDS rows with the 16-B slot XOR-swizzled by (row >> 1) & 7 on the DMA SOURCE side: every 16-lane
+//     ds_read_b128 group of a 32-row fragment covers all 16 slots of the 256-B bank row.
+//
+// Replaces (reference call sites): nn.Linear at vit.py:36,39,59,62,117 and hybrid_CTUNet.py:402-679; 1x1x1 nn.Conv3d at
+// resnet.py:96,100 and hybrid_CTUNet.py:75-83; the ConvTranspose3d panels of get_conv_layer (resnet.py:17-50).
+#include "mma.h"
+#include "dma.h"
+#include "gemm_dma.h"
+
+namespace {
+
+struct WorkItem {
+  int m0, n0, kb, ke;  // tile origin, k-step range [kb, ke)
+};
+
+// y = act(x + bias) + residual -> out / out2 / scattered out, 8 consecutive n of row m (the ctu_epilogue contract)
+__device__ __forceinline__ void epilogue_store8(const ctu_epilogue& ep, bf16* out, int m, int n, float (&x)[8]) {
+  if (ep.bias) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] += ep.bias[n + e];
+  }
+  if (ep.act == 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = gelu_erf(x[e]);
+  }
+  bf16* dst = out;
+  size_t off;
+  if (ep.scatter) {
+    const int tap = n / ep.n_per_tap, co = n - tap * ep.n_per_tap;
+    const int tw = tap % ep.sc_kw;
+    const int tq = tap / ep.sc_kw;
+    const int th = tq % ep.sc_kh, td = tq / ep.sc_kh;
+    int t = m;
+    const int ww = t % ep.sc_W; t /= ep.sc_W;
+    const int hh = t % ep.sc_H; t /= ep.sc_H;
+    const int dd = t % ep.sc_D;
+    const int bb = t / ep.sc_D;
+    const size_t orow = (((size_t)bb * (ep.sc_D * ep.sc_kd) + dd * ep.sc_kd + td) * (ep.sc_H * ep.sc_kh) + hh * ep.sc_kh + th) *
+                            (size_t)(ep.sc_W * ep.sc_kw) + ww * ep.sc_kw + tw;
+    off = orow * ep.ldc + co;
+  } else if (ep.n_split > 0 && n >= ep.n_split) {
+    dst = reinterpret_cast<bf16*>(ep.out2);
+    off = (size_t)m * ep.ldc2 + (n - ep.n_split);
+  } else {
+    off = (size_t)m * ep.ldc + n;
+  }
+  if (ep.residual) {
+    float rr[8];
+    load8(reinterpret_cast<const bf16*>(ep.residual) + off, rr);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] += rr[e];
+  }
+  store8(dst + off, x);
+}
+
+}  // namespace
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(const GemmNtArgs p) {
+  constexpr int BK = 64;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int WM = BM / 2, WN = BN / 2;  // wave tile: WM rows x WN columns (waves 2 x 2)
+  constexpr int MI = WM / 32, NJ = WN / 32;
+  constexpr int APW = BM / 32;     // DMA instructions (8 rows of 128 B each) per wave and stage: A ...
+  constexpr int BPW = BN / 32;     // ... and B
+  constexpr int EPI_LD = 32 + 4;
+  constexpr int EPI_BYTES = 4 * 16 * EPI_LD * 4;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + EPI_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int vid = xcd_remap(blockIdx.x, gridDim.x);
+
+  auto decode = [&](int wi) {
+    WorkItem it;
+    const int tn = wi % p.tiles_n;
+    const int q = wi / p.tiles_n;
+    const int sp = q % p.splitk, tm = q / p.splitk;
+    it.m0 = tm * BM;
+    it.n0 = tn * BN;
+    it.kb = sp * p.ks_per_split;
+    it.ke = min(p.ksteps, it.kb + p.ks_per_split);
+    return it;
+  };
+
+  // this lane's rows / source slots in the DMA instructions of its wave: instruction j covers tile rows 8 j' .. 8 j' + 7
+  // (lane >> 3 picks the row, lane & 7 the LDS slot, which holds source slot (lane & 7) ^ ((row >> 1) & 7))
+  int arow[APW], aslot[APW], brow[BPW], bslot[BPW];
+#pragma unroll
+  for (int j = 0; j < APW; ++j) {
+    arow[j] = 8 * APW * wave + 8 * j + (lane >> 3);
+    aslot[j] = (lane & 7) ^ ((arow[j] >> 1) & 7);
+  }
+#pragma unroll
+  for (int j = 0; j < BPW; ++j) {
+    brow[j] = 8 * BPW * wave + 8 * j + (lane >> 3);
+    bslot[j] = (lane & 7) ^ ((brow[j] >> 1) & 7);
+  }
+
+  auto issue = [&](const WorkItem& it, int ks, int st) {
+    const int k0 = ks * BK;
+    const bool first = k0 < p.C1;
+    const bf16* a = first ? p.a1 : p.a2;
+    const int lda = first ? p.C1 : p.C2;
+    const int ka = first ? k0 : k0 - p.C1;
+    unsigned char* sa = smem + st * STAGE;
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+      const int m = min(it.m0 + arow[j], p.M - 1);  // tail rows repeat the last row; their outputs are never stored
+      dma16(a + (size_t)m * lda + ka + aslot[j] * 8, sa + (APW * wave + j) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+      const int n = min(it.n0 + brow[j], p.N - 1);
+      dma16(p.w + (size_t)n * p.K + k0 + bslot[j] * 8, sa + A_BYTES + (BPW * wave + j) * 1024);
+    }
+  };
+
+  // fragment read offsets inside a stage: row * 128 + ((slot ^ ((row >> 1) & 7)) << 4), slot = 2 kk + h
+  int aoff[MI], boff[NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = wm * WM + i * 32 + r;
+    aoff[i] = row * 128 + ((h ^ ((row >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int row = wn * WN + j * 32 + r;
+    boff[j] = A_BYTES + row * 128 + ((h ^ ((row >> 1) & 7)) << 4);
+  }
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float* stage = reinterpret_cast<float*>(smem + 2 * STAGE) + wave * 16 * EPI_LD;
+  bf16* out = reinterpret_cast<bf16*>(p.out);
+
+  int wi = vid;
+  if (wi >= p.nwork) return;
+  WorkItem cur = decode(wi);
+  int ks = cur.kb, st = 0;
+  issue(cur, ks, 0);
+  while (true) {
+    // stage st has landed in every wave, and every wave is done reading stage st ^ 1
+    wait_vm_then_barrier<0>();
+    const bool last = ks + 1 == cur.ke;
+    WorkItem nxt = cur;
+    int nks = ks + 1;
+    bool have_next = true;
+    if (last) {
+      const int nwi = wi + gridDim.x;
+      if (nwi < p.nwork) { nxt = decode(nwi); nks = nxt.kb; }
+      else have_next = false;
+    }
+    if (have_next) issue(nxt, nks, st ^ 1);
+
+    const unsigned char* sa = smem + st * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 fa[MI], fb[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + (aoff[i] ^ (kk << 5)));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sa + (boff[j] ^ (kk << 5)));
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+
+    if (last) {
+      // epilogue through a wave-private 16 x 32 fp32 patch (outside the DMA ring: the next tile is already in flight)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              stage[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_LD + r] = acc[i][j][8 * half + e];
+            __builtin_amdgcn_wave_barrier();
+            const int mb = cur.m0 + wm * WM + i * 32 + half * 16;
+            const int nb = cur.n0 + wn * WN + j * 32;
+            if (p.splitk > 1) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const int idx = lane + 64 * q;
+                const int row = idx >> 5, col = idx & 31;
+                if (mb + row < p.M && nb + col < p.N)
+                  atomicAdd(p.ws + (size_t)(mb + row) * p.N + nb + col, stage[row * EPI_LD + col]);
+              }
+            } else {
+              const int row = lane >> 2, cv = lane & 3;
+              const int m = mb + row, n = nb + cv * 8;
+              if (m < p.M && n < p.N) {
+                float x[8];
+                load8(&stage[row * EPI_LD + cv * 8], x);
+                epilogue_store8(p.ep, out, m, n, x);
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      if (!have_next) break;
+      wi += gridDim.x;
+      cur = nxt;
+    }
+    ks = nks;
+    st ^= 1;
+  }
+}
+
+int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {
+  // tile choice: the largest tile that still yields ~200 work items for the 512 resident workgroups; the 864-token
+  // ViT trunk (M = 864) gets 64 x 64 tiles rather than a split K with its atomics and second pass
+  const auto items = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  int BM = 128, BN = p.N <= 64 ? 64 : 128;
+  if (items(BM, BN) < 200 && p.splitk <= 1) {
+    BN = 64;
+    if (items(BM, BN) < 200) BM = 64;
+  }
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  p.ksteps = p.K / 64;
+  if (p.splitk > p.ksteps) p.splitk = p.ksteps;
+  if (p.splitk < 1) p.splitk = 1;
+  p.ks_per_split = (p.ksteps + p.splitk - 1) / p.splitk;
+  p.splitk = (p.ksteps + p.ks_per_split - 1) / p.ks_per_split;
+  const int64_t nwork = (int64_t)p.tiles_m * p.tiles_n * p.splitk;
+  if (nwork >= (1ll << 31)) return -1;
+  p.nwork = (int)nwork;
+  const int grid = p.nwork < 512 ? p.nwork : 512;  // two resident workgroups per CU, persistent over the work items
+  if (BM == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 64>), dim3(grid), dim3(256), 0, stream, p);
+  else if (BN == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 64>), dim3(grid), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128>), dim3(grid), dim3(256), 0, stream, p);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// gemm_tn_dma : dw[n][c] += sum_m P[m][n] Q[m][c].  The reduction index m is the ROW of both operands, so both are
+// read "transposed" (ds_read_b64_tr_b16: 8 consecutive rows of one column per lane).  LDS image per stage of 64 rows:
+// 32-column panels [panel][64 rows][32 cols] (64-B rows, plain lane-linear DMA): a transposed read touches
+// 4 consecutive rows x 64 B = one whole 256-B bank row, conflict free without padding or swizzle.
+// Workgroup = TN x TC tile of dw over one row split; 4 waves as 2 x 2; 2 stages; 2 workgroups per CU.
+// Row tail (m >= M): P rows come from the zero page (Q rows are clamped - any finite value times zero).
+// Column tails are clamped too: a column >= N only feeds output rows that are never written.
+// bias_grad (column sums of P) costs one extra MFMA against a fragment of ones in the workgroups of c tile 0.
+// ---------------------------------------------------------------------------------------------------------
+template <int TN, int TC>
+__global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const GemmTnArgs a) {
+  constexpr int BKM = 64;
+  constexpr int PANEL = BKM * 64;              // bytes of one 32-column panel of a stage
+  constexpr int NP = TN / 32, NQ = TC / 32;    // panels
+  constexpr int STAGE = (NP + NQ) * PANEL;
+  constexpr int PI = NP, QI = NQ;              // DMA instructions per wave and stage (4 per panel, 4 waves)
+  constexpr int AI = TN / 64, AJ = TC / 64;    // MFMA tiles per wave
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wc = wave & 1;
+  const int vid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = a.tiles_n * a.tiles_c;
+  const int tile = vid % tiles, split = vid / tiles;  // the tiles of one split sit together on one XCD
+  const int n0 = (tile / a.tiles_c) * TN;
+  const int c0 = (tile % a.tiles_c) * TC;
+  const int m_begin = split * a.rows_per_split;
+  const int m_end = min(a.M, m_begin + a.rows_per_split);
+  const bf16* zero = reinterpret_cast<const bf16*>(g_zero16);
+
+  // this lane's source columns per DMA instruction: instruction q of the wave = (panel, 16-row group) pair
+  // wave w owns instruction indices w + 4 q over the 4 NP (4 NQ) instructions of P (Q)
+  int pcol[PI], qcol[QI];
+  const bf16* qbase[QI];
+  int qld[QI];
+#pragma unroll
+  for (int q = 0; q < PI; ++q) {
+    const int ins = wave + 4 * q, panel = ins >> 2;
+    pcol[q] = min(n0 + panel * 32 + (lane & 3) * 8, a.N - 8);
+  }
+#pragma unroll
+  for (int q = 0; q < QI; ++q) {
+    const int ins = wave + 4 * q, panel = ins >> 2;
+    const int c = min(c0 + panel * 32 + (lane & 3) * 8, a.C - 8);
+    const bool first = c < a.C1;
+    qbase[q] = first ? a.q1 : a.q2;
+    qld[q] = first ? a.C1 : a.C2;
+    qcol[q] = first ? c : c - a.C1;
+  }
+  auto issue = [&](int mb, int st) {
+    unsigned char* dst = smem + st * STAGE;
+#pragma unroll
+    for (int q = 0; q < PI; ++q) {
+      const int ins = wave + 4 * q;
+      const int m = mb + (ins & 3) * 16 + (lane >> 2);
+      dma16(m < m_end ? a.p + (size_t)m * a.ldp + pcol[q] : zero, dst + ins * 1024);
+    }
+#pragma unroll
+    for (int q = 0; q < QI; ++q) {
+      const int ins = wave + 4 * q;
+      const int m = min(mb + (ins & 3) * 16 + (lane >> 2), a.M - 1);
+      dma16(qbase[q] + (size_t)m * qld[q] + qcol[q], dst + NP * PANEL + ins * 1024);
+    }
+  };
+
+  f32x16 acc[AI][AJ], accb[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accb[i][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  }
+  const bool do_bias = a.bias_grad != nullptr && (tile % a.tiles_c) == 0;  // workgroup-uniform
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
+  if (m_begin < m_end) {
+    issue(m_begin, 0);
+    int st = 0;
+    for (int mb = m_begin; mb < m_end; mb += BKM, st ^= 1) {
+      wait_vm_then_barrier<0>();  // stage st landed everywhere; everyone is done with stage st ^ 1
+      if (mb + BKM < m_end) issue(mb + BKM, st ^ 1);
+      const bf16* sp = reinterpret_cast<const bf16*>(smem + st * STAGE);
+      const bf16* sq = sp + NP * (PANEL / 2);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int krow = kk * 16 + h * 8;
+        bf16x8 fa[AI], fb[AJ];
+#pragma unroll
+        for (int i = 0; i < AI; ++i) fa[i] = Mma<bf16>::gather(sp + (wn * AI + i) * (PANEL / 2) + krow * 32 + r, 32);
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) fb[j] = Mma<bf16>::gather(sq + (wc * AJ + j) * (PANEL / 2) + krow * 32 + r, 32);
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+#pragma unroll
+          for (int j = 0; j < AJ; ++j) Mma<bf16>::mma(fa[i], fb[j], acc[i][j]);
+        if (do_bias && wc == 0) {
+#pragma unroll
+          for (int i = 0; i < AI; ++i) Mma<bf16>::mma(fa[i], ones, accb[i]);
+        }
+      }
+    }
+  }
+
+  const bool single = a.splits == 1;
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int n = n0 + (wn * AI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const int c = c0 + (wc * AJ + j) * 32 + r;
+        if (c < a.C) {
+          const size_t o = (size_t)n * a.C + c;
+          if (a.part) a.part[(size_t)split * a.N * a.C + o] = acc[i][j][e];
+          else if (single) a.dw[o] += acc[i][j][e];
+          else atomicAdd(&a.dw[o], acc[i][j][e]);
+        }
+      }
+      if (do_bias && wc == 0 && r == 0) atomicAdd(&a.bias_grad[n], accb[i][e]);
+    }
+  }
+}
+
+int launch_gemm_tn_dma(GemmTnArgs& a, float* ws, int64_t ws_floats, hipStream_t stream) {
+  const auto ntiles = [&](int tn, int tc) { return (int64_t)((a.N + tn - 1) / tn) * ((a.C + tc - 1) / tc); };
+  // 128 x 128 tiles when they alone give the chip enough work or the panel is small and M long (row splits fill the
+  // chip); otherwise 64 x 64
+  int TN = 128, TC = 128;
+  if (a.N <= 64 || a.C <= 64 || (ntiles(128, 128) < 128 && a.M < 8192)) { TN = 64; TC = 64; }
+  a.tiles_n = (a.N + TN - 1) / TN;
+  a.tiles_c = (a.C + TC - 1) / TC;
+  const int64_t tiles = (int64_t)a.tiles_n * a.tiles_c;
+  int splits = tiles >= 384 ? 1 : (int)((512 + tiles - 1) / tiles);
+  const int max_splits = (a.M + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int64_t E = (int64_t)a.N * a.C;
+  a.part = nullptr;
+  const bool two_stage = ws && E <= (1 << 18) && splits >= 8;
+  if (two_stage && (int64_t)splits * E > ws_floats) splits = (int)(ws_floats / E);
+  int rps = (a.M + splits - 1) / splits;
+  rps = ((rps + 63) / 64) * 64;
+  splits = (a.M + rps - 1) / rps;
+  if (two_stage && splits >= 8) a.part = ws;
+  a.rows_per_split = rps;
+  a.splits = splits;
+  const int64_t nwork = tiles * splits;
+  if (nwork >= (1ll << 31)) return -1;
+  if (TN == 128) hipLaunchKernelGGL((gemm_tn_dma_kernel<128, 128>), dim3((unsigned)nwork), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_tn_dma_kernel<64, 64>), dim3((unsigned)nwork), dim3(256), 0, stream, a);
+  return 0;
+}

@@ -12,6 +12,7 @@
 #include "common.h"
 
 #include "mma.h"
+#include "gemm_dma.h"
 
 struct NtArgs {
   const void* a1;
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtArgs p) {
 
 // epilogue of a split-K GEMM: out = act(ws + bias) + residual, ws fp32 [M][N]
 template <typename T>
-__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, T* __restrict__ out,
+__global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ ws, T* __restrict__ out,
                                                             const float* __restrict__ bias, const T* __restrict__ res,
                                                             const int act, const int M, const int N, const int ldc) {
   const int ncg = N >> 3;
@@ -242,6 +243,10 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
     const int n = (int)(i - m * ncg) * 8;
     float x[8];
     load8(ws + m * N + n, x);
+    {  // hand the workspace back zeroed
+      const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      store8(ws + m * N + n, z);
+    }
     if (bias) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] += bias[n + e];
@@ -260,6 +265,33 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
   }
 }
 
+static bool geom_is_plain(const ctu_geom* g) {
+  return g->kd == 1 && g->kh == 1 && g->kw == 1 && g->sd == 1 && g->sh == 1 && g->sw == 1 && g->pd == 0 && g->ph == 0 &&
+         g->pw == 0 && g->Di == g->Do && g->Hi == g->Ho && g->Wi == g->Wo;
+}
+
+// route plain bf16 GEMMs with 64-deep K to the LDS-DMA kernel
+template <typename T> struct NtDma {
+  static bool launch(const void*, const void*, const void*, void*, const ctu_geom*, const ctu_epilogue*, NtArgs&,
+                     hipStream_t) { return false; }
+};
+template <> struct NtDma<bf16> {
+  static bool launch(const void* a1, const void* a2, const void* w, void* out, const ctu_geom* g, const ctu_epilogue* ep,
+                     NtArgs& p, hipStream_t stream) {
+    const int K = g->C1 + g->C2;
+    if (!geom_is_plain(g) || K % 64 != 0 || (g->C2 > 0 && g->C1 % 64 != 0) || ctu_option_generic_gemm()) return false;
+    GemmNtArgs q;
+    q.a1 = reinterpret_cast<const bf16*>(a1); q.a2 = reinterpret_cast<const bf16*>(a2);
+    q.w = reinterpret_cast<const bf16*>(w); q.out = out; q.ep = *ep;
+    q.M = p.M; q.N = g->N; q.K = K; q.C1 = g->C1; q.C2 = g->C2;
+    q.splitk = (ep->splitk > 1 && ep->splitk_ws) ? ep->splitk : 1;
+    q.ws = ep->splitk_ws;
+    if (launch_gemm_nt_dma(q, stream) != 0) return false;
+    p.splitk = q.splitk;
+    return true;
+  }
+};
+
 template <typename T>
 static int launch_nt(const void* a1, const void* a2, const void* w, void* out, const ctu_geom* g,
                      const ctu_epilogue* ep, hipStream_t stream) {
@@ -276,7 +308,9 @@ static int launch_nt(const void* a1, const void* a2, const void* w, void* out, c
   p.its_per_split = (n_it + p.splitk - 1) / p.splitk;
   p.splitk = (n_it + p.its_per_split - 1) / p.its_per_split;
   p.ws = ep->splitk_ws;
-  if (g->N <= 64) {
+  if (NtDma<T>::launch(a1, a2, w, out, g, ep, p, stream)) {
+    // plain bf16 GEMM on the LDS-DMA kernel (gemm_dma.hip); p.splitk holds the split it used
+  } else if (g->N <= 64) {
     p.tiles_n = (g->N + 63) / 64;
     p.nwg = tiles_m * p.tiles_n;
     hipLaunchKernelGGL((igemm_nt_kernel<T, 64>), dim3(p.nwg, p.splitk), dim3(256), 0, stream, p);
@@ -343,6 +377,7 @@ struct TnArgs {
   ctu_geom g;
   int ldp, M, C, taps, rows_per_split, tiles_c;
   unsigned long long magic_w, magic_h, magic_d;  // ceil(2^32 / d)
+  float* part;  // two-stage reduction: [splits][taps][N][C] partial panels written with plain stores (else NULL)
 };
 
 // floor(x / d) for 0 <= x < 2^31: the rounded-up reciprocal over-estimates by at most 1, fixed by one compare
@@ -513,9 +548,10 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnArgs a) {
           const int n = n0 + wn + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
           const int c = c0 + wc + j * 32 + r;
           if (n < N && c < C) {
-            float* dst = &a.dw[((size_t)tap * N + n) * C + c];
-            if (single) *dst += acc[i][j][e];
-            else atomicAdd(dst, acc[i][j][e]);
+            const size_t o = ((size_t)tap * N + n) * C + c;
+            if (a.part) a.part[(size_t)blockIdx.z * a.taps * N * C + o] = acc[i][j][e];
+            else if (single) a.dw[o] += acc[i][j][e];
+            else atomicAdd(&a.dw[o], acc[i][j][e]);
           }
         }
     return;
@@ -533,24 +569,71 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnArgs a) {
   for (int i = tid; i < TN * TC; i += 256) {
     const int n = n0 + i / TC, c = c0 + i % TC;
     if (n < N && c < C) {
-      float* dst = &a.dw[((size_t)tap * N + n) * C + c];
-      if (single) *dst += red[i];  // sole writer of this element
-      else atomicAdd(dst, red[i]);
+      const size_t o = ((size_t)tap * N + n) * C + c;
+      if (a.part) a.part[(size_t)blockIdx.z * a.taps * N * C + o] = red[i];
+      else if (single) a.dw[o] += red[i];  // sole writer of this element
+      else atomicAdd(&a.dw[o], red[i]);
     }
   }
 }
+
+// second stage of a split weight gradient with a small panel: dw[i] += sum_s part[s][i].  Hundreds of row splits
+// adding into the same few thousand addresses serialise in the L2 atomic units (a 256 x 64 panel from 173 splits took
+// 82 us against 10 us of operand traffic); plain partial stores + this pass do not.  grid (E/256, G): group g sums
+// splits g, g+G, ... and adds its subtotal with one atomic (G-way contention at most).
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                        const int64_t E, const int splits) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= E) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const int G = gridDim.y;
+  int sp = blockIdx.y;
+  for (; sp + 3 * G < splits; sp += 4 * G) {
+    s0 += part[(size_t)sp * E + i];
+    s1 += part[(size_t)(sp + G) * E + i];
+    s2 += part[(size_t)(sp + 2 * G) * E + i];
+    s3 += part[(size_t)(sp + 3 * G) * E + i];
+  }
+  for (; sp < splits; sp += G) s0 += part[(size_t)sp * E + i];
+  const float t = (s0 + s1) + (s2 + s3);
+  if (G == 1) dw[i] += t;
+  else atomicAdd(&dw[i], t);
+}
+
+// route plain bf16 weight gradients to the LDS-DMA kernel (gemm_dma.hip)
+template <typename T> struct TnDma {
+  static bool launch(const TnArgs&, float*, int64_t, hipStream_t) { return false; }
+};
+template <> struct TnDma<bf16> {
+  static bool launch(const TnArgs& a, float* ws, int64_t ws_floats, hipStream_t stream) {
+    if (!geom_is_plain(&a.g) || ctu_option_generic_gemm()) return false;
+    GemmTnArgs q;
+    q.p = reinterpret_cast<const bf16*>(a.p); q.q1 = reinterpret_cast<const bf16*>(a.q1);
+    q.q2 = reinterpret_cast<const bf16*>(a.q2); q.dw = a.dw; q.bias_grad = a.bias_grad;
+    q.ldp = a.ldp; q.M = a.M; q.N = a.g.N; q.C = a.C; q.C1 = a.g.C1; q.C2 = a.g.C2;
+    if (launch_gemm_tn_dma(q, ws, ws_floats, stream) != 0) return false;
+    if (q.part) {
+      const int64_t E = (int64_t)q.N * q.C;
+      const int G = q.splits >= 64 ? 8 : (q.splits >= 16 ? 4 : 1);
+      hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((E + 255) / 256), G), dim3(256), 0, stream, q.part, a.dw, E,
+                         q.splits);
+    }
+    return true;
+  }
+};
 
 static unsigned long long magic32(int d) { return ((1ull << 32) + (unsigned long long)d - 1) / (unsigned long long)d; }
 
 template <typename T>
 static int launch_tn(const void* p, int ldp, const void* q1, const void* q2, float* dw, float* bias_grad,
-                     const ctu_geom* g, hipStream_t stream) {
+                     const ctu_geom* g, float* ws, int64_t ws_floats, hipStream_t stream) {
   TnArgs a;
   a.p = p; a.q1 = q1; a.q2 = q2; a.dw = dw; a.bias_grad = bias_grad; a.g = *g; a.ldp = ldp;
   a.M = (int)((int64_t)g->B * g->Do * g->Ho * g->Wo);
   a.C = g->C1 + g->C2;
   a.taps = g->kd * g->kh * g->kw;
   a.magic_w = magic32(g->Wo); a.magic_h = magic32(g->Ho); a.magic_d = magic32(g->Do);
+  if (TnDma<T>::launch(a, ws, ws_floats, stream)) return ctu_check_launch("igemm_tn");
   const bool small_n = g->N <= 32, small_c = a.C <= 32;
   const bool big = g->N >= 128 && a.C >= 128;  // 128x128 wave-tiled variant
   const int TN = big ? 128 : (small_n ? 32 : 64), TC = big ? 128 : (small_c ? 32 : 64);
@@ -567,6 +650,18 @@ static int launch_tn(const void* p, int ldp, const void* q1, const void* q2, flo
   int rps = (a.M + splits - 1) / splits;
   rps = ((rps + 63) / 64) * 64;
   splits = (a.M + rps - 1) / rps;
+  // small panel + many splits: partial panels in the workspace and a reduction pass instead of same-address atomics
+  const int64_t E = (int64_t)a.taps * g->N * a.C;
+  a.part = nullptr;
+  if (ws && E <= (1 << 18) && splits >= 8) {
+    if ((int64_t)splits * E > ws_floats) {
+      splits = (int)(ws_floats / E);
+      rps = (a.M + splits - 1) / splits;
+      rps = ((rps + 63) / 64) * 64;
+      splits = (a.M + rps - 1) / rps;
+    }
+    if (splits >= 8) a.part = ws;
+  }
   a.rows_per_split = rps;
   dim3 grid(tiles_n * a.tiles_c, a.taps, splits);
   if (big) hipLaunchKernelGGL((igemm_tn_kernel<T, 128, 128, true>), grid, dim3(256), 0, stream, a);
@@ -574,18 +669,23 @@ static int launch_tn(const void* p, int ldp, const void* q1, const void* q2, flo
   else if (small_n) hipLaunchKernelGGL((igemm_tn_kernel<T, 32, 64>), grid, dim3(256), 0, stream, a);
   else if (small_c) hipLaunchKernelGGL((igemm_tn_kernel<T, 64, 32>), grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((igemm_tn_kernel<T, 64, 64>), grid, dim3(256), 0, stream, a);
+  if (a.part) {
+    const int G = splits >= 64 ? 8 : (splits >= 16 ? 4 : 1);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((E + 255) / 256), G), dim3(256), 0, stream, a.part, dw, E, splits);
+  }
   return ctu_check_launch("igemm_tn");
 }
 
 extern "C" int ctu_igemm_tn(ctu_dtype dtype, const void* p, int32_t ldp, const void* q1, const void* q2, float* dw,
-                            float* bias_grad, const ctu_geom* g, ctu_stream_t stream) {
+                            float* bias_grad, const ctu_geom* g, float* ws, int64_t ws_floats, ctu_stream_t stream) {
   if (int rc = check_geom(g)) return rc;
   CTU_REQUIRE(p && q1 && dw, "null pointer");
   CTU_REQUIRE(g->C2 == 0 || q2, "C2 > 0 needs q2");
   CTU_REQUIRE(ldp >= g->N && ldp % 8 == 0, "ldp must be >= N and a multiple of 8");
   CTU_REQUIRE(g->kd * g->kh * g->kw <= 65535, "too many taps");
-  CTU_DISPATCH(dtype, return launch_tn<float>(p, ldp, q1, q2, dw, bias_grad, g, (hipStream_t)stream),
-               return launch_tn<bf16>(p, ldp, q1, q2, dw, bias_grad, g, (hipStream_t)stream));
+  CTU_REQUIRE(ws_floats >= 0 && (ws_floats == 0 || ws), "bad workspace");
+  CTU_DISPATCH(dtype, return launch_tn<float>(p, ldp, q1, q2, dw, bias_grad, g, ws, ws_floats, (hipStream_t)stream),
+               return launch_tn<bf16>(p, ldp, q1, q2, dw, bias_grad, g, ws, ws_floats, (hipStream_t)stream));
 }
 
 // ---------------------------------------------------------------------------------------------------------

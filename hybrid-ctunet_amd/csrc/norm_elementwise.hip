@@ -50,8 +50,9 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ x, 
 }
 
 // (sum(x-K), sum(x-K)^2) in fp64 -> (mean, rstd) in fp32
+// The accumulators are handed back zeroed, so one persistent workspace serves every call without a memset launch.
 template <typename T>
-__global__ __launch_bounds__(256) void in_finalize_kernel(const T* __restrict__ x, const double* __restrict__ acc,
+__global__ __launch_bounds__(256) void in_finalize_kernel(const T* __restrict__ x, double* __restrict__ acc,
                                                           float* __restrict__ stats, const int B, const int64_t S,
                                                           const int C) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -61,6 +62,8 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const T* __restrict__ 
   const double k = (double)(float)x[((size_t)b * S) * C + c];
   const double m = acc[(size_t)i * 2] * inv_s;
   const double var = fmax(acc[(size_t)i * 2 + 1] * inv_s - m * m, 0.0);
+  acc[(size_t)i * 2] = 0.0;
+  acc[(size_t)i * 2 + 1] = 0.0;
   stats[(size_t)i * 2] = (float)(k + m);
   stats[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)NORM_EPS));
 }
@@ -74,19 +77,26 @@ __device__ __forceinline__ void in_mean_rstd(const float* stats, int b, int C, i
   }
 }
 
-// y = act((x - mean) * rstd + residual); one thread per 8-channel vector, grid-stride over B*S*C/8 vectors
+// y = act((x - mean) * rstd + residual).  grid (gx, B) with gx * 256 a multiple of C/8: a thread keeps ONE 8-channel
+// column group of ONE batch item, so mean / rstd are loaded once and the loop is a pure stream.
 template <typename T>
 __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
-                                                       const T* __restrict__ res, T* __restrict__ y, const int B,
-                                                       const int64_t S, const int C, const int act) {
+                                                       const T* __restrict__ res, T* __restrict__ y, const int64_t S,
+                                                       const int C, const int act) {
   const int ncg = C >> 3;
-  const int64_t nvec = (int64_t)B * S * ncg;
-  const float inv_s = 1.0f / (float)S;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-    const int cg = (int)(i % ncg);
-    const int b = (int)(i / ((int64_t)S * ncg));
-    float mean[8], rstd[8], v[8];
-    in_mean_rstd(stats, b, C, cg * 8, inv_s, mean, rstd);
+  const int b = blockIdx.y;
+  const int64_t nvec = S * ncg;
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int cg = (int)(i0 % ncg);
+  float mean[8], rstd[8];
+  in_mean_rstd(stats, b, C, cg * 8, 0.f, mean, rstd);
+  const size_t base = (size_t)b * S * C;
+  x += base;
+  y += base;
+  if (res) res += base;
+  for (int64_t i = i0; i < nvec; i += stride) {
+    float v[8];
     load8(x + i * 8, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean[e]) * rstd[e];
@@ -163,22 +173,43 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
   }
 }
 
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)); same thread -> column-group mapping as in_apply_kernel.
+// `clear` (optional) is another sums buffer that no launch still reads - the previous call's: it is zeroed here so the
+// two buffers can alternate between calls without a memset launch.
 template <typename T>
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const T* __restrict__ y, const float* __restrict__ stats,
                                                            const double* __restrict__ sums, T* __restrict__ dx,
-                                                           T* __restrict__ dres, const int B, const int64_t S,
-                                                           const int C, const int act) {
+                                                           T* __restrict__ dres, const int64_t S, const int C,
+                                                           const int act, double* __restrict__ clear, const int clear_n) {
   const int ncg = C >> 3;
-  const int64_t nvec = (int64_t)B * S * ncg;
-  const float inv_s = 1.0f / (float)S;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-    const int cg = (int)(i % ncg);
-    const int b = (int)(i / ((int64_t)S * ncg));
-    float mean[8], rstd[8], g[8], xv[8];
-    in_mean_rstd(stats, b, C, cg * 8, inv_s, mean, rstd);
+  const int b = blockIdx.y;
+  const int64_t nvec = S * ncg;
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  if (clear && b == 0)
+    for (int64_t i = i0; i < clear_n; i += stride) clear[i] = 0.0;
+  const int cg = (int)(i0 % ncg);
+  float mean[8], rstd[8], m1[8], m2[8];
+  in_mean_rstd(stats, b, C, cg * 8, 0.f, mean, rstd);
+  const double inv_s = 1.0 / (double)S;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    m1[e] = (float)(sums[((size_t)b * C + cg * 8 + e) * 2] * inv_s);
+    m2[e] = (float)(sums[((size_t)b * C + cg * 8 + e) * 2 + 1] * inv_s);
+  }
+  const size_t base = (size_t)b * S * C;
+  dy += base;
+  x += base;
+  dx += base;
+  if (y) y += base;
+  if (dres) dres += base;
+  for (int64_t i = i0; i < nvec; i += stride) {
+    float g[8], xv[8], xh[8];
     load8(dy + i * 8, g);
     load8(x + i * 8, xv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xh[e] = (xv[e] - mean[e]) * rstd[e];
     if (act) {
       if (y) {
         float yv[8];
@@ -187,20 +218,25 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
         for (int e = 0; e < 8; ++e) g[e] = yv[e] > 0.f ? g[e] : g[e] * LRELU_SLOPE;
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = (xv[e] - mean[e]) * rstd[e] > 0.f ? g[e] : g[e] * LRELU_SLOPE;
+        for (int e = 0; e < 8; ++e) g[e] = xh[e] > 0.f ? g[e] : g[e] * LRELU_SLOPE;
       }
     }
     if (dres) store8(dres + i * 8, g);
     float o[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float m1 = (float)(sums[((size_t)b * C + cg * 8 + e) * 2] / (double)S);
-      const float m2 = (float)(sums[((size_t)b * C + cg * 8 + e) * 2 + 1] / (double)S);
-      const float xh = (xv[e] - mean[e]) * rstd[e];
-      o[e] = rstd[e] * (g[e] - m1 - xh * m2);
-    }
+    for (int e = 0; e < 8; ++e) o[e] = rstd[e] * (g[e] - m1[e] - xh[e] * m2[e]);
     store8(dx + i * 8, o);
   }
+}
+
+// grid.x for the streaming kernels: ~8192 workgroups in total, a multiple of C/8 so a thread's column group is fixed
+static unsigned in_stream_grid(int64_t S, int C, int B) {
+  const int ncg = C / 8;
+  int64_t g = (S * ncg + 255) / 256;
+  const int64_t cap = 8192 / (B > 0 ? B : 1) > 0 ? 8192 / (B > 0 ? B : 1) : 1;
+  if (g > cap) g = cap;
+  g = ((g + ncg - 1) / ncg) * ncg;
+  return (unsigned)g;
 }
 
 static int check_in(const void* x, int B, int64_t S, int C) {
@@ -242,13 +278,13 @@ extern "C" int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, 
                             int32_t B, int64_t S, int32_t C, int32_t act, ctu_stream_t stream) {
   if (int rc = check_in(x, B, S, C)) return rc;
   CTU_REQUIRE(stats && y, "null pointer");
-  const unsigned grid = grid_for((int64_t)B * S * (C / 8), 256);
+  const dim3 grid(in_stream_grid(S, C, B), B);
   hipStream_t s = (hipStream_t)stream;
   CTU_DISPATCH(dtype,
-               hipLaunchKernelGGL(in_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, stats,
-                                  (const float*)residual, (float*)y, B, S, C, act),
-               hipLaunchKernelGGL(in_apply_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, stats,
-                                  (const bf16*)residual, (bf16*)y, B, S, C, act));
+               hipLaunchKernelGGL(in_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, stats,
+                                  (const float*)residual, (float*)y, S, C, act),
+               hipLaunchKernelGGL(in_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, stats,
+                                  (const bf16*)residual, (bf16*)y, S, C, act));
   return ctu_check_launch("in_apply");
 }
 
@@ -269,16 +305,17 @@ extern "C" int ctu_in_bwd_reduce(ctu_dtype dtype, const void* dy, const void* x,
 
 extern "C" int ctu_in_bwd_apply(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
                                 const double* sums, void* dx, void* dres, int32_t B, int64_t S, int32_t C, int32_t act,
-                                ctu_stream_t stream) {
+                                double* clear_ws, int32_t clear_n, ctu_stream_t stream) {
   if (int rc = check_in(x, B, S, C)) return rc;
   CTU_REQUIRE(dy && stats && sums && dx, "null pointer");
-  const unsigned grid = grid_for((int64_t)B * S * (C / 8), 256);
+  CTU_REQUIRE(clear_n >= 0 && (clear_n == 0 || clear_ws) && clear_ws != sums, "bad clear workspace");
+  const dim3 grid(in_stream_grid(S, C, B), B);
   hipStream_t s = (hipStream_t)stream;
   CTU_DISPATCH(dtype,
-               hipLaunchKernelGGL(in_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy,
-                                  (const float*)x, (const float*)y, stats, sums, (float*)dx, (float*)dres, B, S, C, act),
-               hipLaunchKernelGGL(in_bwd_apply_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)dy,
-                                  (const bf16*)x, (const bf16*)y, stats, sums, (bf16*)dx, (bf16*)dres, B, S, C, act));
+               hipLaunchKernelGGL(in_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x,
+                                  (const float*)y, stats, sums, (float*)dx, (float*)dres, S, C, act, clear_ws, clear_n),
+               hipLaunchKernelGGL(in_bwd_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, (const bf16*)x,
+                                  (const bf16*)y, stats, sums, (bf16*)dx, (bf16*)dres, S, C, act, clear_ws, clear_n));
   return ctu_check_launch("in_bwd_apply");
 }
 

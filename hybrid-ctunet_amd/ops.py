@@ -102,12 +102,29 @@ def _plain_geom(M, K, N) -> Geom:
     return _geom(1, (M, 1, 1), (M, 1, 1), K, 0, N)
 
 
-def _splitk_for(M: int, N: int, K: int) -> int:
-    """Split-K factor for a plain GEMM: few output tiles (the 864-token ViT trunk) and a long reduction."""
+def _splitk_for(M: int, N: int, K: int, dma: bool = False) -> int:
+    """Split-K factor for a plain GEMM: few output tiles (the 864-token ViT trunk) and a long reduction.  The LDS-DMA
+    kernel (bf16, K % 64 == 0) first drops to 64 x 64 tiles; it splits only when even those leave the chip idle."""
+    if dma:
+        items = ((M + 63) // 64) * ((N + 63) // 64)
+        if items >= 128 or K < 1024:
+            return 1
+        return max(1, min(K // 256, (255 + items) // items))
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles >= 128 or K < 512:
         return 1
     return max(1, min(16, K // 128, 512 // tiles))
+
+
+_SPLITK_WS = {}
+
+
+def _splitk_workspace(device, n):
+    """Persistent fp32 split-K workspace (zero between calls: the finish kernel hands it back zeroed)."""
+    ws = _SPLITK_WS.get(device)
+    if ws is None or ws.numel() < n:
+        ws = _SPLITK_WS[device] = torch.zeros(max(n, 1 << 22), dtype=torch.float32, device=device)
+    return ws
 
 
 def _epi(ldc, bias=None, residual=None, act=0, out2=None, n_split=0, ldc2=0, scatter=None, splitk_ws=None,
@@ -143,14 +160,28 @@ def _igemm_nt(x1, x2, w, out, g: Geom, e: Epilogue):
     call("ctu_igemm_nt", dcode(x1.dtype), ptr(x1), ptr(x2), ptr(w), ptr(out), g, e, stream())
 
 
+_TN_WS = {}
+
+
+def _tn_workspace(device):
+    """Persistent scratch (16 Mi floats) for the two-stage reduction of small weight-gradient panels; contents are
+    irrelevant between calls (every partial is written before it is read), single compute stream."""
+    ws = _TN_WS.get(device)
+    if ws is None:
+        ws = _TN_WS[device] = torch.empty(1 << 24, dtype=torch.float32, device=device)
+    return ws
+
+
 def _igemm_tn(p, ldp, q1, q2, dw, g: Geom, bias_grad=None):
-    call("ctu_igemm_tn", dcode(p.dtype), ptr(p), ldp, ptr(q1), ptr(q2), ptr(dw), ptr(bias_grad), g, stream())
+    ws = _tn_workspace(p.device)
+    call("ctu_igemm_tn", dcode(p.dtype), ptr(p), ldp, ptr(q1), ptr(q2), ptr(dw), ptr(bias_grad), g, ptr(ws), ws.numel(),
+         stream())
 
 
 def _plain_gemm(x, w, out, M, K, N, bias=None, residual=None, act=0):
     """out[M,N] = act(x[M,K] @ w[N,K]^T + bias) + residual, with split-K when there are few tiles and a long K."""
-    sk = _splitk_for(M, N, K)
-    ws = torch.zeros((M, N), dtype=torch.float32, device=x.device) if sk > 1 else None
+    sk = _splitk_for(M, N, K, dma=x.dtype == torch.bfloat16 and K % 64 == 0)
+    ws = _splitk_workspace(x.device, M * N) if sk > 1 else None
     _igemm_nt(x, None, w, out, _plain_geom(M, K, N),
               _epi(N, bias=bias, residual=residual, act=act, splitk_ws=ws, splitk=sk))
 
@@ -430,7 +461,7 @@ class InstanceNormFn(torch.autograd.Function):
         _check_act(x)
         B, C = x.shape[0], x.shape[-1]
         S = x.numel() // (B * C)
-        acc = torch.zeros((B, C, 2), dtype=torch.float64, device=x.device)
+        acc = _in_workspace(x.device, B * C * 2)[0]  # zero on entry, handed back zeroed by ctu_in_stats
         stats = torch.empty((B, C, 2), dtype=torch.float32, device=x.device)
         y = torch.empty_like(x)
         dc = dcode(x.dtype)
@@ -448,14 +479,33 @@ class InstanceNormFn(torch.autograd.Function):
         gy = gy.contiguous()
         B, C = x.shape[0], x.shape[-1]
         S = x.numel() // (B * C)
-        sums = torch.zeros((B, C, 2), dtype=torch.float64, device=x.device)
+        ws = _in_workspace(x.device, B * C * 2)
+        # two sums buffers alternate: this call reduces into the clean one and its apply kernel zeroes the other,
+        # which the previous call left dirty and nothing reads any more (stream order)
+        sums, dirty, dirty_n = ws[1 + ws[3]], ws[2 - ws[3]], ws[4]
         gx = torch.empty_like(x)
         gres = torch.empty_like(x) if ctx.has_res else None
         dc = dcode(x.dtype)
         call("ctu_in_bwd_reduce", dc, ptr(gy), ptr(x), ptr(y), ptr(stats), ptr(sums), B, S, C, ctx.act, stream())
         call("ctu_in_bwd_apply", dc, ptr(gy), ptr(x), ptr(y), ptr(stats), ptr(sums), ptr(gx), ptr(gres), B, S, C,
-             ctx.act, stream())
+             ctx.act, ptr(dirty), dirty_n, stream())
+        ws[3] ^= 1
+        ws[4] = B * C * 2
         return gx, gres, None
+
+
+_IN_WS = {}
+
+
+def _in_workspace(device, n):
+    """Persistent fp64 InstanceNorm accumulators of one device (single compute stream): [fwd acc, bwd sums A, bwd sums B,
+    index of the clean bwd buffer, dirty entries of the other].  The kernels keep them zero between uses."""
+    ws = _IN_WS.get(device)
+    if ws is None or ws[0].numel() < n:
+        size = max(n, 1 << 15)
+        ws = [torch.zeros(size, dtype=torch.float64, device=device) for _ in range(3)] + [0, 0]
+        _IN_WS[device] = ws
+    return ws
 
 
 def instance_norm(x, residual=None, act=False):

@@ -36,8 +36,9 @@ typedef void* ctu_stream_t; /* hipStream_t */
 
 int ctu_abi_version(void);
 const char* ctu_last_error(void);
-/* Test hook (process-wide): "attn_valu" = 1 makes ctu_attn_fwd/_bwd use the VALU reference kernels even where the MFMA
- * kernels apply, so both implementations can be checked against the oracle in one process. */
+/* Test hooks (process-wide): "attn_valu" = 1 makes ctu_attn_fwd/_bwd use the VALU reference kernels even where the MFMA
+ * kernels apply; "generic_gemm" = 1 keeps plain bf16 GEMMs on the generic implicit-GEMM kernels instead of the LDS-DMA
+ * GEMM kernels - so both implementations can be checked against the oracle in one process. */
 int ctu_set_option(const char* name, int32_t value);
 
 /* Geometry of an implicit GEMM over a channels-last volume.
@@ -75,7 +76,8 @@ typedef struct ctu_epilogue {
   int32_t sc_D, sc_H, sc_W, sc_kd, sc_kh, sc_kw;
   /* split-K for GEMMs with few output tiles and a long reduction (the ViT trunk: 864 tokens, K up to 3072):
    * splitk > 1 with a ZEROED fp32 workspace [M][N] makes `splitk` workgroups per tile sum partial tiles into the
-   * workspace; a second kernel applies bias/act/residual and writes `out`.  Plain epilogue only. */
+   * workspace; a second kernel applies bias/act/residual, writes `out` and hands the workspace back ZEROED (one
+   * persistent workspace serves every call on a stream without a memset).  Plain epilogue only. */
   int32_t splitk;
   float* splitk_ws;
 } ctu_epilogue;
@@ -91,9 +93,12 @@ int ctu_igemm_nt(ctu_dtype dtype, const void* a1, const void* a2, const void* w,
 /* Weight gradient:  dw[tap][n][c] += sum_m P[m][n] * Q[gather(m,tap)][c]   (fp32 atomics into a zeroed panel).
  * P has g->N columns (leading dim ldp) over the row space, Q1/Q2 are the gathered tensors (C1/C2 channels).
  * bias_grad (optional, fp32 [N], zeroed): += column sums of P, i.e. the bias gradient of the same layer, computed
- * from the P vectors the kernel stages anyway (no second pass over dY). */
+ * from the P vectors the kernel stages anyway (no second pass over dY).
+ * ws (optional, fp32, ws_floats entries, contents irrelevant): scratch for a two-stage reduction, used when the panel
+ * is small (taps*N*C <= 2^18) and the row space is split >= 8 ways - partial panels are stored there and summed by a
+ * second pass instead of hundreds of atomics landing on the same addresses. */
 int ctu_igemm_tn(ctu_dtype dtype, const void* p, int32_t ldp, const void* q1, const void* q2, float* dw,
-                 float* bias_grad, const ctu_geom* g, ctu_stream_t stream);
+                 float* bias_grad, const ctu_geom* g, float* ws, int64_t ws_floats, ctu_stream_t stream);
 
 /* Cin == 1 convolutions (vit_encoder0.conv1 1->64 3x3x3, hybrid_CTUNet.py:57-65; ResNet stem 7x7x7 s(2,2,1),
  * resnet.py:150-155).  x: [B][Di][Hi][Wi] ; w: fp32 [taps][N] ; out: [M][N].  kernel 1x1x1 (ResBlock.conv3 shortcut), 3x3x3 or 7x7x7. */
@@ -130,21 +135,24 @@ int ctu_colsum(ctu_dtype dtype, const void* x, int64_t M, int32_t N, int32_t ld,
                ctu_stream_t stream);
 
 /* K6/K7 InstanceNorm3d (eps 1e-5, no affine) fused with residual add and LeakyReLU(0.01)
- * (resnet.py:97-124,156-157,198; hybrid_CTUNet.py:84-104).  x: [B][S][C]; acc_ws: fp64 [B][C][2] workspace zeroed
- * by the caller; stats: fp32 [B][C][2] receives (mean, rstd).  Sums are shifted by the channel's first voxel and
+ * (resnet.py:97-124,156-157,198; hybrid_CTUNet.py:84-104).  x: [B][S][C]; acc_ws: fp64 [B][C][2] workspace, zero on
+ * entry and handed back ZEROED (one persistent workspace serves every call on a stream without a memset); stats:
+ * fp32 [B][C][2] receives (mean, rstd).  Sums are shifted by the channel's first voxel and
  * accumulated in fp64 (no E[x^2]-E[x]^2 cancellation; the deep IN stack amplifies statistic noise ~1000x).  y = act((x-mean)*rstd + residual). */
 int ctu_in_stats(ctu_dtype dtype, const void* x, int32_t B, int64_t S, int32_t C, double* acc_ws, float* stats,
                  ctu_stream_t stream);
 int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, const void* residual, void* y, int32_t B,
                  int64_t S, int32_t C, int32_t act, ctu_stream_t stream);
 /* backward: g = dy * act'(y) (y may be NULL when no residual was added: then sign(y) == sign(xhat) and the third
- * input stream is skipped); sums[b][c] = (sum g, sum g*xhat), fp64, zeroed by caller;
- * dx = rstd*(g - s1/S - xhat*s2/S); dres = g when dres != NULL. */
+ * input stream is skipped); sums[b][c] = (sum g, sum g*xhat), fp64, zero on entry;
+ * dx = rstd*(g - s1/S - xhat*s2/S); dres = g when dres != NULL.  ctu_in_bwd_apply also zeroes clear_ws[0..clear_n)
+ * (optional, must differ from sums): pass the sums buffer of the PREVIOUS call on the stream so two buffers can
+ * alternate without a memset launch. */
 int ctu_in_bwd_reduce(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
                       double* sums, int32_t B, int64_t S, int32_t C, int32_t act, ctu_stream_t stream);
 int ctu_in_bwd_apply(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
                      const double* sums, void* dx, void* dres, int32_t B, int64_t S, int32_t C, int32_t act,
-                     ctu_stream_t stream);
+                     double* clear_ws, int32_t clear_n, ctu_stream_t stream);
 
 /* K8 LayerNorm (eps 1e-5, affine) (vit.py:35,55,116,118; hybrid_CTUNet.py:456,518,630-631).
  * x,y: [rows][dim]; mean_rstd: fp32 [rows][2]; dgamma/dbeta: fp32 [dim], accumulated (atomics). */

@@ -71,6 +71,10 @@ CASES = {
     "tn_big": lambda: [tn(442368, 512, 128), tn(442368, 128, 512), tn(442368, 384, 128), tn(442368, 128, 32),
                        tn(442368, 32, 128), tn(55296, 768, 256), tn(55296, 256, 64), tn(1769472, 16, 64),
                        tn(6912, 1536, 512)],
+    "tn_skinny": lambda: [tn(55296, 256, 64), tn(55296, 64, 256), tn(442368, 128, 32), tn(442368, 32, 128),
+                          tn(1769472, 16, 64), tn(6912, 512, 128), tn(6912, 128, 512)],
+    "tn_probe": lambda: [tn(13824, 256, 64), tn(55296, 256, 64), tn(221184, 256, 64), tn(55296, 64, 64),
+                         tn(55296, 128, 64), tn(55296, 256, 32), tn(55296, 256, 128), tn(55296, 64, 32)],
     "nt_trunk": lambda: [nt(864, 768, 3072), nt(864, 3072, 768), nt(864, 768, 768), nt(864, 2304, 768)],
     "nt_big": lambda: [nt(442368, 512, 128), nt(442368, 128, 512), nt(442368, 128, 32), nt(442368, 32, 128),
                        nt(6912, 128, 512), nt(1769472, 16, 64), nt(55296, 256, 64)],
