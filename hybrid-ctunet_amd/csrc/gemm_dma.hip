@@ -67,8 +67,12 @@ __device__ __forceinline__ void epilogue_store8(const ctu_epilogue& ep, bf16* ou
 
 }  // namespace
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(const GemmNtArgs p) {
+// R = ring depth (stages of 64 k): R - 1 stages are in flight while one is computed.  A step of a small tile is a
+// handful of MFMAs, far less than one DMA latency, so small tiles (and launches with at most one workgroup per CU)
+// take a deeper ring; the wait is a counted vmcnt that leaves the younger stages in flight (epilogue stores pending
+// on the same counter only make it wait for more, never less: loads retire in order among themselves).
+template <int BM, int BN, int R>
+__global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) void gemm_nt_dma_kernel(const GemmNtArgs p) {
   constexpr int BK = 64;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int STAGE = A_BYTES + B_BYTES;
@@ -78,7 +82,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(const GemmNtArgs p)
   constexpr int BPW = BN / 32;     // ... and B
   constexpr int EPI_LD = 32 + 4;
   constexpr int EPI_BYTES = 4 * 16 * EPI_LD * 4;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + EPI_BYTES];
+  constexpr int IPW = APW + BPW;   // DMA instructions per wave and stage
+  static_assert((R - 2) * IPW <= 8, "counted vmcnt switch covers 0..8");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[R * STAGE + EPI_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -152,27 +158,33 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(const GemmNtArgs p)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float* stage = reinterpret_cast<float*>(smem + 2 * STAGE) + wave * 16 * EPI_LD;
+  float* stage = reinterpret_cast<float*>(smem + R * STAGE) + wave * 16 * EPI_LD;
   bf16* out = reinterpret_cast<bf16*>(p.out);
 
-  int wi = vid;
-  if (wi >= p.nwork) return;
-  WorkItem cur = decode(wi);
-  int ks = cur.kb, st = 0;
-  issue(cur, ks, 0);
-  while (true) {
-    // stage st has landed in every wave, and every wave is done reading stage st ^ 1
-    wait_vm_then_barrier<0>();
-    const bool last = ks + 1 == cur.ke;
-    WorkItem nxt = cur;
-    int nks = ks + 1;
-    bool have_next = true;
-    if (last) {
-      const int nwi = wi + gridDim.x;
-      if (nwi < p.nwork) { nxt = decode(nwi); nks = nxt.kb; }
-      else have_next = false;
+  if (vid >= p.nwork) return;
+  // two cursors over the flat sequence of (work item, k step) stages of this workgroup: issue runs R - 1 ahead of compute
+  int wi = vid, iwi = vid;
+  WorkItem cur = decode(wi), icur = cur;
+  int ks = cur.kb, iks = cur.kb;
+  bool idone = false;
+  auto issue_next = [&](int slot) {
+    issue(icur, iks, slot);
+    if (++iks == icur.ke) {
+      iwi += gridDim.x;
+      if (iwi < p.nwork) { icur = decode(iwi); iks = icur.kb; }
+      else idone = true;
     }
-    if (have_next) issue(nxt, nks, st ^ 1);
+  };
+  int ahead = 0, st = 0, ist = 0;  // stages issued but not yet computed; compute slot; next issue slot
+#pragma unroll 1
+  for (int q = 0; q < R - 1 && !idone; ++q) { issue_next(ist); ist = ist + 1 == R ? 0 : ist + 1; ++ahead; }
+  while (true) {
+    // stage st has landed in every wave (the ahead - 1 younger ones may still be in flight), and every wave is done
+    // reading the slot computed in the previous iteration - the one refilled next
+    wait_vm_then_barrier_n((ahead - 1) * IPW);
+    if (!idone) { issue_next(ist); ist = ist + 1 == R ? 0 : ist + 1; ++ahead; }
+    const bool last = ks + 1 == cur.ke;
+    --ahead;
 
     const unsigned char* sa = smem + st * STAGE;
 #pragma unroll
@@ -227,12 +239,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(const GemmNtArgs p)
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-      if (!have_next) break;
       wi += gridDim.x;
-      cur = nxt;
+      if (wi >= p.nwork) break;
+      cur = decode(wi);
+      ks = cur.kb;
+    } else {
+      ++ks;
     }
-    ks = nks;
-    st ^= 1;
+    st = st + 1 == R ? 0 : st + 1;
   }
 }
 
@@ -255,10 +269,13 @@ int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {
   const int64_t nwork = (int64_t)p.tiles_m * p.tiles_n * p.splitk;
   if (nwork >= (1ll << 31)) return -1;
   p.nwork = (int)nwork;
-  const int grid = p.nwork < 512 ? p.nwork : 512;  // two resident workgroups per CU, persistent over the work items
-  if (BM == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 64>), dim3(grid), dim3(256), 0, stream, p);
-  else if (BN == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 64>), dim3(grid), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128>), dim3(grid), dim3(256), 0, stream, p);
+  const bool one_per_cu = p.nwork <= 256;  // a single workgroup per CU may take the whole LDS for a deeper ring
+  const int grid = p.nwork < 512 ? p.nwork : 512;  // else two resident workgroups per CU, persistent over the work items
+  const dim3 g(grid), b(256);
+  if (BM == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 64, 4>), g, b, 0, stream, p);
+  else if (BN == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 64, 2>), g, b, 0, stream, p);
+  else if (one_per_cu) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128, 3>), g, b, 0, stream, p);
+  else hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128, 2>), g, b, 0, stream, p);
   return 0;
 }
 
@@ -272,15 +289,16 @@ int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {
 // Column tails are clamped too: a column >= N only feeds output rows that are never written.
 // bias_grad (column sums of P) costs one extra MFMA against a fragment of ones in the workgroups of c tile 0.
 // ---------------------------------------------------------------------------------------------------------
-template <int TN, int TC>
-__global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const GemmTnArgs a) {
+template <int TN, int TC, int R>
+__global__ __launch_bounds__(256, (R * (TN + TC) * 128 > 80 * 1024) ? 1 : 2) void gemm_tn_dma_kernel(const GemmTnArgs a) {
   constexpr int BKM = 64;
   constexpr int PANEL = BKM * 64;              // bytes of one 32-column panel of a stage
   constexpr int NP = TN / 32, NQ = TC / 32;    // panels
   constexpr int STAGE = (NP + NQ) * PANEL;
   constexpr int PI = NP, QI = NQ;              // DMA instructions per wave and stage (4 per panel, 4 waves)
   constexpr int AI = TN / 64, AJ = TC / 64;    // MFMA tiles per wave
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+  static_assert((R - 2) * (PI + QI) <= 8, "counted vmcnt switch covers 0..8");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[R * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -345,12 +363,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const GemmTnArgs a)
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
-  if (m_begin < m_end) {
-    issue(m_begin, 0);
-    int st = 0;
-    for (int mb = m_begin; mb < m_end; mb += BKM, st ^= 1) {
-      wait_vm_then_barrier<0>();  // stage st landed everywhere; everyone is done with stage st ^ 1
-      if (mb + BKM < m_end) issue(mb + BKM, st ^ 1);
+  {
+    // R - 1 stages in flight ahead of the one computed; counted vmcnt leaves the younger ones pending
+    const int nst = (m_end - m_begin + BKM - 1) / BKM;
+    int issued = 0, st = 0, ist = 0;
+#pragma unroll 1
+    for (; issued < R - 1 && issued < nst; ++issued) { issue(m_begin + issued * BKM, ist); ist = ist + 1 == R ? 0 : ist + 1; }
+    for (int sidx = 0; sidx < nst; ++sidx, st = st + 1 == R ? 0 : st + 1) {
+      // stage st landed in every wave; every wave is done with the slot computed last iteration (refilled next)
+      wait_vm_then_barrier_n((issued - sidx - 1) * (PI + QI));
+      if (issued < nst) { issue(m_begin + issued * BKM, ist); ist = ist + 1 == R ? 0 : ist + 1; ++issued; }
       const bf16* sp = reinterpret_cast<const bf16*>(smem + st * STAGE);
       const bf16* sq = sp + NP * (PANEL / 2);
 #pragma unroll
@@ -404,23 +426,36 @@ int launch_gemm_tn_dma(GemmTnArgs& a, float* ws, int64_t ws_floats, hipStream_t 
   a.tiles_n = (a.N + TN - 1) / TN;
   a.tiles_c = (a.C + TC - 1) / TC;
   const int64_t tiles = (int64_t)a.tiles_n * a.tiles_c;
-  int splits = tiles >= 384 ? 1 : (int)((512 + tiles - 1) / tiles);
+  // row splits: aim at ~512 workgroups, but every split costs a pass over the whole panel - bound that reduction
+  // traffic (two-stage: splits x E x 8 B at ~4 TB/s) by half the MMA time it can save (~0.45 us per 64-row stage)
+  const int64_t E = (int64_t)a.N * a.C;
+  const int64_t stages = (a.M + 63) / 64;
+  int splits = tiles >= 256 ? 1 : (int)((512 + tiles - 1) / tiles);
+  if (E > (1 << 18)) {
+    const double cap = (double)stages * 0.45 * 4.0e6 / (16.0 * (double)E);
+    if (splits > (int)cap) splits = (int)cap;
+  }
   const int max_splits = (a.M + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  const int64_t E = (int64_t)a.N * a.C;
   a.part = nullptr;
-  const bool two_stage = ws && E <= (1 << 18) && splits >= 8;
-  if (two_stage && (int64_t)splits * E > ws_floats) splits = (int)(ws_floats / E);
+  const int two_stage_min = E > (1 << 18) ? 2 : 8;  // small panels with a few splits: plain atomics are cheaper
+  bool two_stage = ws && splits >= two_stage_min;
+  if (two_stage && (int64_t)splits * E > ws_floats) {
+    if (E > (1 << 18)) two_stage = false;  // large panel that does not fit: atomics
+    else splits = (int)(ws_floats / E);
+  }
   int rps = (a.M + splits - 1) / splits;
   rps = ((rps + 63) / 64) * 64;
   splits = (a.M + rps - 1) / rps;
-  if (two_stage && splits >= 8) a.part = ws;
+  if (two_stage && splits >= two_stage_min) a.part = ws;
   a.rows_per_split = rps;
   a.splits = splits;
   const int64_t nwork = tiles * splits;
   if (nwork >= (1ll << 31)) return -1;
-  if (TN == 128) hipLaunchKernelGGL((gemm_tn_dma_kernel<128, 128>), dim3((unsigned)nwork), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_tn_dma_kernel<64, 64>), dim3((unsigned)nwork), dim3(256), 0, stream, a);
+  const dim3 g((unsigned)nwork), b(256);
+  if (TN == 64) hipLaunchKernelGGL((gemm_tn_dma_kernel<64, 64, 4>), g, b, 0, stream, a);
+  else if (nwork <= 256) hipLaunchKernelGGL((gemm_tn_dma_kernel<128, 128, 3>), g, b, 0, stream, a);  // one per CU: deeper ring
+  else hipLaunchKernelGGL((gemm_tn_dma_kernel<128, 128, 2>), g, b, 0, stream, a);
   return 0;
 }

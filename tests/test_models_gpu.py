@@ -145,6 +145,9 @@ def _rel(got, ref):
     return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-300))
 
 
+_STATE_CACHE = {}
+
+
 def _run_model(H, golden_dir, name, precision):
     """Runs the HIP path on the B=2 batch (seeds 1000, 1001) and returns, per quantity, a triple
     (err of the HIP path vs the reference run in fp64, err of the fp32 reference vs the same fp64 value,
@@ -156,7 +159,10 @@ def _run_model(H, golden_dir, name, precision):
     man = json.load(open(os.path.join(golden_dir, f"manifest_{name}.json")))
     m = H.build_model(kind, model_depth=depth)
     assert {k: list(v.shape) for k, v in m.state_dict().items()} == man
-    m.load_state_dict({k: O.synthetic_tensor(k, s) for k, s in man.items()}, strict=True)
+    if name not in _STATE_CACHE:  # the fp32 and the bf16 test of a model share the seeded state dict (CPU RNG time)
+        _STATE_CACHE.clear()
+        _STATE_CACHE[name] = {k: O.synthetic_tensor(k, s) for k, s in man.items()}
+    m.load_state_dict(_STATE_CACHE[name], strict=True)
     m = m.cuda().set_precision(precision)
     x0, y0 = O.synthetic_batch(1, seed=1000)
     x1, y1 = O.synthetic_batch(1, seed=1001)
@@ -219,7 +225,7 @@ def test_whole_model_fp32_matches_reference_golden(H, golden_dir, name):
             assert e_mine <= max(5e-3, 2 * e_ref), (k, e_mine, e_ref)
 
 
-@pytest.mark.parametrize("name", ["cunet101", "tunet", "ctunet101"])
+@pytest.mark.parametrize("name", ["ctunet101", "cunet101", "tunet"])
 def test_whole_model_bf16_drift(H, golden_dir, name):
     """bf16 operands / fp32 accumulate (BASELINE configs 2-4): drift vs the reference-in-fp64 value is REPORTED; the
     gate is loose and on aggregate quantities (loss, median gradient-norm error) because point-wise logits of the
