@@ -31,7 +31,7 @@ class Epilogue(C.Structure):
     _fields_ = [("bias", _vp), ("residual", _vp), ("act", _i32), ("ldc", _i32), ("out2", _vp), ("n_split", _i32),
                 ("ldc2", _i32), ("scatter", _i32), ("n_per_tap", _i32), ("sc_D", _i32), ("sc_H", _i32),
                 ("sc_W", _i32), ("sc_kd", _i32), ("sc_kh", _i32), ("sc_kw", _i32), ("splitk", _i32),
-                ("splitk_ws", _vp)]
+                ("w_kn", _i32), ("splitk_ws", _vp)]
 
 
 class AttnGeom(C.Structure):
@@ -70,7 +70,7 @@ _SIGS = {
     "ctu_dicece_fwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp] + [_i32] * 8 + [_vp, _vp],
     "ctu_dicece_finalize": [_vp, _i32, _i32, _i64, _f32, _f32, _f32, _vp, _vp],
     "ctu_dicece_bwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp] + [_i32] * 8 + [_vp, _f32, _f32, _f32, _vp, _vp, _vp],
-    "ctu_adamw": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, C.POINTER(_i64), _i32, _vp],
+    "ctu_adamw": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, C.POINTER(_i64), _i32, _vp],
     "ctu_cast": [_vp, _i32, _vp, _i32, _i64, _vp],
     "ctu_set_option": [C.c_char_p, _i32],
 }

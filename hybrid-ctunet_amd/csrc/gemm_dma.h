@@ -5,7 +5,8 @@
 struct GemmNtArgs {
   const bf16* a1;  // [M][C1]
   const bf16* a2;  // [M][C2] (k >= C1), or NULL
-  const bf16* w;   // [N][K], K = C1 + C2
+  const bf16* w;   // [N][K], K = C1 + C2; or, with w_kn, [K][N] (reduction-major)
+  int w_kn;
   void* out;
   ctu_epilogue ep;
   int M, N, K, C1, C2;

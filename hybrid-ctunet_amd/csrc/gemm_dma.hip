@@ -71,7 +71,10 @@ __device__ __forceinline__ void epilogue_store8(const ctu_epilogue& ep, bf16* ou
 // handful of MFMAs, far less than one DMA latency, so small tiles (and launches with at most one workgroup per CU)
 // take a deeper ring; the wait is a counted vmcnt that leaves the younger stages in flight (epilogue stores pending
 // on the same counter only make it wait for more, never less: loads retire in order among themselves).
-template <int BM, int BN, int R>
+// BT = true ("NN"): W is stored reduction-major, W[k][n] with leading dimension N - the data gradient of a Linear /
+// 1x1x1 conv reads the forward weight [N_fwd][K_fwd] as is, no transposed copy.  Its B tile is staged as 32-column
+// panels [panel][64 k rows][32 n] (64-B rows, plain DMA) and read transposed, exactly like the TN kernel's operands.
+template <int BM, int BN, int R, bool BT>
 __global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) void gemm_nt_dma_kernel(const GemmNtArgs p) {
   constexpr int BK = 64;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -114,8 +117,14 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) voi
   }
 #pragma unroll
   for (int j = 0; j < BPW; ++j) {
-    brow[j] = 8 * BPW * wave + 8 * j + (lane >> 3);
-    bslot[j] = (lane & 7) ^ ((brow[j] >> 1) & 7);
+    if constexpr (BT) {  // instruction (panel, 16-row group): brow = k row inside the stage, bslot = first column
+      const int ins = BPW * wave + j;
+      brow[j] = (ins & 3) * 16 + (lane >> 2);
+      bslot[j] = (ins >> 2) * 32 + (lane & 3) * 8;
+    } else {
+      brow[j] = 8 * BPW * wave + 8 * j + (lane >> 3);
+      bslot[j] = (lane & 7) ^ ((brow[j] >> 1) & 7);
+    }
   }
 
   auto issue = [&](const WorkItem& it, int ks, int st) {
@@ -132,8 +141,13 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) voi
     }
 #pragma unroll
     for (int j = 0; j < BPW; ++j) {
-      const int n = min(it.n0 + brow[j], p.N - 1);
-      dma16(p.w + (size_t)n * p.K + k0 + bslot[j] * 8, sa + A_BYTES + (BPW * wave + j) * 1024);
+      if constexpr (BT) {
+        const int n = min(it.n0 + bslot[j], p.N - 8);  // columns past N feed only outputs that are never stored
+        dma16(p.w + (size_t)(k0 + brow[j]) * p.N + n, sa + A_BYTES + (BPW * wave + j) * 1024);
+      } else {
+        const int n = min(it.n0 + brow[j], p.N - 1);
+        dma16(p.w + (size_t)n * p.K + k0 + bslot[j] * 8, sa + A_BYTES + (BPW * wave + j) * 1024);
+      }
     }
   };
 
@@ -147,7 +161,8 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) voi
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int row = wn * WN + j * 32 + r;
-    boff[j] = A_BYTES + row * 128 + ((h ^ ((row >> 1) & 7)) << 4);
+    if constexpr (BT) boff[j] = A_BYTES + (wn * NJ + j) * 4096 + (h * 8 * 32 + r) * 2;  // panel, k row 8 h, column r
+    else boff[j] = A_BYTES + row * 128 + ((h ^ ((row >> 1) & 7)) << 4);
   }
 
   f32x16 acc[MI][NJ];
@@ -193,7 +208,10 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) voi
 #pragma unroll
       for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + (aoff[i] ^ (kk << 5)));
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sa + (boff[j] ^ (kk << 5)));
+      for (int j = 0; j < NJ; ++j) {
+        if constexpr (BT) fb[j] = Mma<bf16>::gather(reinterpret_cast<const bf16*>(sa + boff[j] + kk * 16 * 64), 32);
+        else fb[j] = *reinterpret_cast<const bf16x8*>(sa + (boff[j] ^ (kk << 5)));
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -272,10 +290,17 @@ int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {
   const bool one_per_cu = p.nwork <= 256;  // a single workgroup per CU may take the whole LDS for a deeper ring
   const int grid = p.nwork < 512 ? p.nwork : 512;  // else two resident workgroups per CU, persistent over the work items
   const dim3 g(grid), b(256);
-  if (BM == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 64, 4>), g, b, 0, stream, p);
-  else if (BN == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 64, 2>), g, b, 0, stream, p);
-  else if (one_per_cu) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128, 3>), g, b, 0, stream, p);
-  else hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128, 2>), g, b, 0, stream, p);
+  if (p.w_kn) {
+    if (BM == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 64, 4, true>), g, b, 0, stream, p);
+    else if (BN == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 64, 2, true>), g, b, 0, stream, p);
+    else if (one_per_cu) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128, 3, true>), g, b, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128, 2, true>), g, b, 0, stream, p);
+  } else {
+    if (BM == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 64, 4, false>), g, b, 0, stream, p);
+    else if (BN == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 64, 2, false>), g, b, 0, stream, p);
+    else if (one_per_cu) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128, 3, false>), g, b, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128, 2, false>), g, b, 0, stream, p);
+  }
   return 0;
 }
 

@@ -243,7 +243,8 @@ struct SkipRanges {
   int n;
 };
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                    float* __restrict__ m, float* __restrict__ v, const int64_t n,
+                                                    float* __restrict__ m, float* __restrict__ v, bf16* __restrict__ mirror,
+                                                    const int64_t n,
                                                     const float lr, const float b1, const float b2, const float eps,
                                                     const float wd, const float inv_bc1, const float inv_sqrt_bc2,
                                                     const SkipRanges skip) {
@@ -265,6 +266,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       *reinterpret_cast<f32x4*>(p + i4) = pp;
       *reinterpret_cast<f32x4*>(m + i4) = mm;
       *reinterpret_cast<f32x4*>(v + i4) = vv;
+      if (mirror) {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        bf16x4 q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = (bf16)pp[e];
+        *reinterpret_cast<bf16x4*>(mirror + i4) = q;  // i4 % 4 == 0: 8-byte aligned
+      }
     } else {
       for (int64_t i = i4; i < n && i < i4 + 4; ++i) {
         bool sk = false;
@@ -276,12 +284,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         const float vv = b2 * v[i] + (1.0f - b2) * gg * gg;
         pp -= lr * inv_bc1 * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
         p[i] = pp; m[i] = mm; v[i] = vv;
+        if (mirror) mirror[i] = (bf16)pp;
       }
     }
   }
 }
 
-extern "C" int ctu_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+extern "C" int ctu_adamw(float* p, const float* g, float* m, float* v, void* mirror_bf16, int64_t n, float lr, float beta1, float beta2,
                          float eps, float weight_decay, int32_t step, const int64_t* skip_host, int32_t n_skip,
                          ctu_stream_t stream) {
   CTU_REQUIRE(p && g && m && v && n > 0 && step > 0, "adamw: bad args");
@@ -293,6 +302,6 @@ extern "C" int ctu_adamw(float* p, const float* g, float* m, float* v, int64_t n
   for (int k = 0; k < n_skip; ++k) { sk.r[k][0] = skip_host[2 * k]; sk.r[k][1] = skip_host[2 * k + 1]; }
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), sk);
+                     reinterpret_cast<bf16*>(mirror_bf16), n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), sk);
   return ctu_check_launch("adamw");
 }

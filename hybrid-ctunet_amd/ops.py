@@ -54,6 +54,40 @@ def _packed(param: torch.Tensor, kind: str, dtype: torch.dtype, builder):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# bf16 parameter mirrors: train.FusedAdamW keeps a bf16 copy of every parameter current from inside its update kernel
+# and registers the per-parameter views here; the bf16 GEMMs then take Linear / 1x1x1 conv weights from the mirror
+# instead of casting them every step.  A mirror is used only while the parameter object is untouched since the last
+# sync (version counter) and no invisible write happened (generation, bumped by invalidate_bf16_mirrors()).
+# ---------------------------------------------------------------------------------------------------------------
+_bf16_mirrors = {}
+_mirror_gen = 0
+
+
+def mirror_generation() -> int:
+    return _mirror_gen
+
+
+def invalidate_bf16_mirrors():
+    """Call after writing parameters behind torch's back other than through FusedAdamW.step() (e.g. a broadcast into
+    the flat buffer)."""
+    global _mirror_gen
+    _mirror_gen += 1
+
+
+def register_bf16_mirror(param: torch.Tensor, view: torch.Tensor):
+    pid = id(param)
+    _bf16_mirrors[pid] = (weakref.ref(param, lambda _r, pid=pid: _bf16_mirrors.pop(pid, None)), view,
+                          (param._version, param.data_ptr(), _mirror_gen))
+
+
+def _bf16_weight(param: torch.Tensor):
+    ent = _bf16_mirrors.get(id(param))
+    if ent is not None and ent[0]() is param and ent[2] == (param._version, param.data_ptr(), _mirror_gen):
+        return ent[1]
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # direct gradient sinks: a training harness that owns pre-zeroed, persistent fp32 gradient storage (train.FlatParams)
 # registers (parameter storage address -> callback).  Weight-gradient kernels whose output layout equals the
 # parameter layout (Linear / 1x1x1 conv weights, biases) then accumulate straight into `param.grad` and call the
@@ -128,8 +162,9 @@ def _splitk_workspace(device, n):
 
 
 def _epi(ldc, bias=None, residual=None, act=0, out2=None, n_split=0, ldc2=0, scatter=None, splitk_ws=None,
-         splitk=1) -> Epilogue:
+         splitk=1, w_kn=0) -> Epilogue:
     e = Epilogue()
+    e.w_kn = w_kn
     e.splitk = splitk if splitk_ws is not None else 1
     e.splitk_ws = ptr(splitk_ws)
     e.bias = ptr(bias)
@@ -178,12 +213,27 @@ def _igemm_tn(p, ldp, q1, q2, dw, g: Geom, bias_grad=None):
          stream())
 
 
-def _plain_gemm(x, w, out, M, K, N, bias=None, residual=None, act=0):
+def _plain_gemm(x, w, out, M, K, N, bias=None, residual=None, act=0, w_kn=0):
     """out[M,N] = act(x[M,K] @ w[N,K]^T + bias) + residual, with split-K when there are few tiles and a long K."""
     sk = _splitk_for(M, N, K, dma=x.dtype == torch.bfloat16 and K % 64 == 0)
     ws = _splitk_workspace(x.device, M * N) if sk > 1 else None
     _igemm_nt(x, None, w, out, _plain_geom(M, K, N),
-              _epi(N, bias=bias, residual=residual, act=act, splitk_ws=ws, splitk=sk))
+              _epi(N, bias=bias, residual=residual, act=act, splitk_ws=ws, splitk=sk, w_kn=w_kn))
+
+
+USE_W_KN = True  # tests clear this together with the "generic_gemm" hook (the generic kernels need W transposed)
+
+
+def _linear_weight(weight, w2, dtype):
+    """[N][K] weight in the activation dtype: the parameter itself (fp32), its optimizer-maintained bf16 mirror, or a
+    cached cast."""
+    if dtype == torch.float32 and w2.is_contiguous():
+        return w2
+    if dtype == torch.bfloat16:
+        m = _bf16_weight(weight)
+        if m is not None:
+            return m
+    return _packed(weight, "lin_f", dtype, lambda: w2.detach().to(dtype).contiguous())
 
 
 class LinearFn(torch.autograd.Function):
@@ -197,8 +247,7 @@ class LinearFn(torch.autograd.Function):
         N, K = weight.shape[0], weight[0].numel()
         M = x.numel() // K
         w2 = weight.reshape(N, K)
-        wf = w2 if x.dtype == torch.float32 and w2.is_contiguous() else _packed(
-            weight, "lin_f", x.dtype, lambda: w2.detach().to(x.dtype).contiguous())
+        wf = _linear_weight(weight, w2, x.dtype)
         pre = None
         out = torch.empty((*x.shape[:-1], N), dtype=x.dtype, device=x.device)
         if act == 1 and any(ctx.needs_input_grad[:3]):
@@ -229,9 +278,13 @@ class LinearFn(torch.autograd.Function):
             call("ctu_gelu_bwd", dcode(gy.dtype), ptr(gy), ptr(pre), ptr(g), gy.numel(), stream())
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wd = _packed(weight, "lin_d", x.dtype, lambda: weight.detach().reshape(N, K).t().to(x.dtype).contiguous())
             gx = torch.empty_like(x)
-            _plain_gemm(g, wd, gx, M, N, K)
+            if USE_W_KN and x.dtype == torch.bfloat16 and N % 64 == 0 and K % 8 == 0:
+                # dX = dY @ W: the LDS-DMA GEMM reads the forward weight [N][K] reduction-major, no transposed copy
+                _plain_gemm(g, _linear_weight(weight, weight.reshape(N, K), x.dtype), gx, M, N, K, w_kn=1)
+            else:
+                wd = _packed(weight, "lin_d", x.dtype, lambda: weight.detach().reshape(N, K).t().to(x.dtype).contiguous())
+                _plain_gemm(g, wd, gx, M, N, K)
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         # accumulate straight into persistent .grad storage when the harness registered it (see register_grad_sink)
         gw_buf, gw_done = _direct_grad(weight) if ctx.needs_input_grad[1] else (None, None)

@@ -216,6 +216,22 @@ class FusedAdamW:
         self.step_count = 0
         self.param_groups = [{"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]
         self._static_skip = None
+        # bf16 copy of the parameters, kept current by the AdamW kernel itself: the bf16 GEMMs read layer weights from it
+        self.mirror = torch.empty(self.flat.total, dtype=torch.bfloat16, device=self.flat.flat.device) \
+            if self.flat.flat.is_cuda else None
+        self._mirror_stamp = None
+        self.sync_mirror()
+
+    def sync_mirror(self):
+        """Full fp32 -> bf16 refresh + (re)registration of the per-parameter views; needed only after the parameters
+        were modified by something other than step() (load_state_dict, a broadcast into the flat buffer, ...)."""
+        if self.mirror is None:
+            return
+        f = self.flat
+        self.mirror.copy_(f.flat)
+        for p, o in zip(f.params, f.offsets):
+            ops.register_bf16_mirror(p, self.mirror[o:o + p.numel()])
+        self._mirror_stamp = (ops.mirror_generation(), tuple(p._version for p in f.params))
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat.zero_grad()
@@ -236,9 +252,11 @@ class FusedAdamW:
             arr[2 * k], arr[2 * k + 1] = a, b
         f = self.flat
         lr = self.param_groups[0]["lr"]
-        call("ctu_adamw", ptr(f.flat), ptr(f.grad), ptr(self.m), ptr(self.v), f.total, lr, self.betas[0], self.betas[1],
-             self.eps, self.weight_decay, self.step_count, arr, len(skip), stream())
+        call("ctu_adamw", ptr(f.flat), ptr(f.grad), ptr(self.m), ptr(self.v), ptr(self.mirror), f.total, lr, self.betas[0],
+             self.betas[1], self.eps, self.weight_decay, self.step_count, arr, len(skip), stream())
         ops.bump_weights_epoch()
+        if self.mirror is not None and self._mirror_stamp != (ops.mirror_generation(), tuple(p._version for p in f.params)):
+            self.sync_mirror()  # someone else wrote parameters since the last sync (grad-less ones would stay stale)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -287,6 +305,7 @@ class DataParallel(nn.Module):
         if broadcast and self.world > 1:
             dist.broadcast(f.flat, src=0, group=self.pg)  # DDP ctor semantics: rank 0's parameters win
             ops.bump_weights_epoch()
+            ops.invalidate_bf16_mirrors()
 
     def forward(self, *a, **kw):
         return self.module(*a, **kw)

@@ -79,6 +79,10 @@ typedef struct ctu_epilogue {
    * workspace; a second kernel applies bias/act/residual, writes `out` and hands the workspace back ZEROED (one
    * persistent workspace serves every call on a stream without a memset).  Plain epilogue only. */
   int32_t splitk;
+  /* W layout of a plain GEMM (1 tap, stride 1): 0 = [N][K] (row per output column), 1 = [K][N] (reduction-major):
+   * the data gradient of a Linear / 1x1x1 conv then reads the forward weight as stored instead of a transposed copy.
+   * Only with dtype bf16, K % 64 == 0 and N % 8 == 0 (the LDS-DMA GEMM); anything else is CTU_ERR_ARG. */
+  int32_t w_kn;
   float* splitk_ws;
 } ctu_epilogue;
 
@@ -228,8 +232,9 @@ int ctu_dicece_bwd(ctu_dtype dtype, const void* logits, int32_t ldl, const float
 
 /* K15 fused AdamW over one flat fp32 buffer (torch.optim.AdamW semantics, main_CTUNet.py:192-193).
  * skip: up to 16 [begin,end) element ranges left untouched (parameters whose .grad is None this step,
- * trainer_CTUNet.py:88-89 + torch's "skip if grad is None"). */
-int ctu_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+ * trainer_CTUNet.py:88-89 + torch's "skip if grad is None").  mirror_bf16 (optional, bf16 [n]): receives the updated
+ * parameters rounded to bf16 - the GEMM kernels then read layer weights from it and no per-step cast pass exists. */
+int ctu_adamw(float* p, const float* g, float* m, float* v, void* mirror_bf16, int64_t n, float lr, float beta1, float beta2,
               float eps, float weight_decay, int32_t step, const int64_t* skip_host, int32_t n_skip,
               ctu_stream_t stream);
 /* fp32 <-> dtype casts and fills */

@@ -69,10 +69,12 @@ def test_linear(ops, dtype, M, K, N, bias, act, res, gemm):
     if gemm == "generic" and (dtype == torch.float32 or K % 64 or N % 64):
         pytest.skip("this case runs on the generic kernels anyway")
     _lib.call("ctu_set_option", b"generic_gemm", 1 if gemm == "generic" else 0)
+    ops.USE_W_KN = gemm != "generic"
     try:
         _linear_case(ops, dtype, M, K, N, bias, act, res)
     finally:
         _lib.call("ctu_set_option", b"generic_gemm", 0)
+        ops.USE_W_KN = True
 
 
 def _linear_case(ops, dtype, M, K, N, bias, act, res):
