@@ -29,6 +29,7 @@ struct HaloArgs {
   void* out2;
   int B, D, H, W, C1, C2, N, n_split, ldc, ldc2;
   int nbd, nbh, nbw, ntn;  // brick grid, 32-wide n tiles in the whole panel
+  double* in_acc;          // optional [B][N][2]: += (sum y, sum y^2) per batch item and channel (InstanceNorm statistics)
 };
 
 template <typename T, int NT>
@@ -313,6 +314,52 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_dma_kernel(const HaloArgs p
   }
   wait_vm_then_barrier<0>();  // the tail refetches have landed; LDS is free for the epilogue
 
+  if (p.in_acc) {
+    // InstanceNorm statistics of this output, taken from the fp32 accumulators: the separate pass that re-reads the
+    // tensor from HBM (in_stats_kernel) disappears.  Lane (r, h) sums its 2 x 16 rows of column r per n tile, the two
+    // lane halves are combined by a shuffle, the four waves through LDS, then one fp64 atomic pair per channel and brick.
+    float* red = reinterpret_cast<float*>(smem + 20 * 1024);  // [4 waves][NT * 32 columns][2], beyond the staging tiles
+    const bool full = d0 + HB_D <= p.D && h0 + HB_H <= p.H && w0 + HB_W <= p.W;  // brick entirely inside the volume
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float v = acc[i][j][e];
+          if (!full) {
+            int hh, ww;
+            halo_row_to_hw((e & 3) + 8 * (e >> 2) + 4 * h, hh, ww);
+            if (d0 + wave >= p.D || h0 + 4 * i + hh >= p.H || w0 + ww >= p.W) v = 0.f;
+          }
+          s1 += v;
+          s2 += v * v;
+        }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (h == 0) {
+        red[(wave * NT * 32 + j * 32 + r) * 2] = s1;
+        red[(wave * NT * 32 + j * 32 + r) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < NT * 32) {
+      const int n = nt0 * 32 + tid;
+      if (n < p.N) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) {
+          t1 += red[(wv * NT * 32 + tid) * 2];
+          t2 += red[(wv * NT * 32 + tid) * 2 + 1];
+        }
+        atomicAdd(&p.in_acc[((size_t)b * p.N + n) * 2], (double)t1);
+        atomicAdd(&p.in_acc[((size_t)b * p.N + n) * 2 + 1], (double)t2);
+      }
+    }
+    __syncthreads();  // red is inside the region the staging tiles of other waves do not touch, but keep phases apart
+  }
+
   float* stage = reinterpret_cast<float*>(smem) + wave * 32 * STAGE_LD;
   bf16* out = reinterpret_cast<bf16*>(p.out);
   bf16* out2 = reinterpret_cast<bf16*>(p.out2);
@@ -378,7 +425,7 @@ static int launch_halo(const HaloArgs& p, hipStream_t s) {
 
 extern "C" int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, const void* wfrag, void* out, void* out2,
                               int32_t B, int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N,
-                              int32_t n_split, int32_t ldc, int32_t ldc2, ctu_stream_t stream) {
+                              int32_t n_split, int32_t ldc, int32_t ldc2, double* in_acc, ctu_stream_t stream) {
   CTU_REQUIRE(x1 && wfrag && out, "conv3_halo: null pointer");
   CTU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3_halo: bad dims");
   CTU_REQUIRE(C1 > 0 && C1 % 32 == 0 && C2 >= 0 && C2 % 32 == 0 && (C2 == 0 || x2), "conv3_halo: C1, C2 must be multiples of 32");
@@ -387,6 +434,10 @@ extern "C" int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, c
   HaloArgs p;
   p.x1 = x1; p.x2 = x2; p.wfrag = wfrag; p.out = out; p.out2 = out2;
   p.B = B; p.D = D; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.N = N; p.n_split = n_split; p.ldc = ldc; p.ldc2 = ldc2;
+  p.in_acc = in_acc;
+  CTU_REQUIRE(!in_acc || (dtype == CTU_BF16 && n_split == 0 &&
+                          (int64_t)B * D * H * W * (C1 > C2 ? C1 : C2) < (1ll << 31)),
+              "conv3_halo: fused InstanceNorm statistics need the bf16 LDS-DMA kernel (no split, < 2^31 elements)");
   p.nbd = (D + HB_D - 1) / HB_D; p.nbh = (H + HB_H - 1) / HB_H; p.nbw = (W + HB_W - 1) / HB_W;
   p.ntn = (N + 31) / 32;
   CTU_REQUIRE((int64_t)B * p.nbd * p.nbh * p.nbw < (1ll << 31), "conv3_halo: too many bricks");

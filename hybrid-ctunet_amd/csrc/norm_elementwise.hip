@@ -68,6 +68,19 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const T* __restrict__ 
   stats[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)NORM_EPS));
 }
 
+// same from UNSHIFTED sums (sum x, sum x^2) accumulated by a producer's epilogue (ctu_conv3_halo in_acc); bf16 path only
+__global__ __launch_bounds__(256) void in_finalize_raw_kernel(double* __restrict__ acc, float* __restrict__ stats,
+                                                              const int n, const double inv_s) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double m = acc[(size_t)i * 2] * inv_s;
+  const double var = fmax(acc[(size_t)i * 2 + 1] * inv_s - m * m, 0.0);
+  acc[(size_t)i * 2] = 0.0;
+  acc[(size_t)i * 2 + 1] = 0.0;
+  stats[(size_t)i * 2] = (float)m;
+  stats[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)NORM_EPS));
+}
+
 __device__ __forceinline__ void in_mean_rstd(const float* stats, int b, int C, int c0, float /*inv_s*/, float (&mean)[8],
                                              float (&rstd)[8]) {
 #pragma unroll
@@ -272,6 +285,13 @@ extern "C" int ctu_in_stats(ctu_dtype dtype, const void* x, int32_t B, int64_t S
                  hipLaunchKernelGGL(in_finalize_kernel<bf16>, fgrid, dim3(256), 0, s, (const bf16*)x, acc, stats, B, S, C);
                });
   return ctu_check_launch("in_stats");
+}
+
+extern "C" int ctu_in_finalize(int32_t B, int64_t S, int32_t C, double* acc, float* stats, ctu_stream_t stream) {
+  CTU_REQUIRE(B > 0 && S > 0 && C > 0 && acc && stats, "in_finalize: bad args");
+  hipLaunchKernelGGL(in_finalize_raw_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, acc, stats,
+                     B * C, 1.0 / (double)S);
+  return ctu_check_launch("in_finalize");
 }
 
 extern "C" int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, const void* residual, void* y,

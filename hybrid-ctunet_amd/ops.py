@@ -327,8 +327,13 @@ class ConvFn(torch.autograd.Function):
         out = torch.empty((B, *dout, N), dtype=x1.dtype, device=x1.device)
         if _halo_ok(k, stride, padding) and C1 % 32 == 0 and C2 % 32 == 0:
             wfr = _packed(weight, "conv_hf", x1.dtype, lambda: _pack_frag(weight, N, K, taps, K * taps, taps, 1, 0, x1.dtype))
+            acc = None
+            if FUSE_IN_STATS and x1.dtype == torch.bfloat16 and B * D * H * W * max(C1, C2) < (1 << 31):
+                # InstanceNorm statistics of the output from the conv epilogue (consumed by instance_norm, if it follows)
+                acc = _in_acc_take(x1.device, B * N * 2)
             call("ctu_conv3_halo", dcode(x1.dtype), ptr(x1), ptr(x2), ptr(wfr), ptr(out), None, B, D, H, W, C1, C2, N, 0,
-                 N, 0, stream())
+                 N, 0, ptr(acc[1]) if acc is not None else None, stream())
+            ctx.in_acc = acc
         else:
             wf = _packed(weight, "conv_f", x1.dtype,
                          lambda: _pack(weight, (taps, N, K), (1, K * taps, taps), x1.dtype))
@@ -336,6 +341,10 @@ class ConvFn(torch.autograd.Function):
             _igemm_nt(x1, x2, wf, out, g, _epi(N))
         ctx.save_for_backward(x1, x2, weight)
         ctx.cfg = (stride, padding, k, dout)
+        if getattr(ctx, "in_acc", None) is not None:
+            global _last_in_acc
+            _last_in_acc = ctx.in_acc
+            ctx.in_acc = None
         return out
 
     @staticmethod
@@ -356,7 +365,7 @@ class ConvFn(torch.autograd.Function):
                 wfr = _packed(weight, "conv_hd", x1.dtype,
                               lambda: _pack_frag(weight, K, N, taps, taps, K * taps, 1, 1, x1.dtype))
                 call("ctu_conv3_halo", dcode(x1.dtype), ptr(gy), None, ptr(wfr), ptr(g1), ptr(g2), B, D, H, W, N, 0, K,
-                     C1 if x2 is not None else 0, C1, C2, stream())
+                     C1 if x2 is not None else 0, C1, C2, None, stream())
             else:
                 # dX[v][c] = sum_t sum_n dY[(v + p - t)/s][n] W[n][c][t]  ->  panel [t][c][n]
                 wd = _packed(weight, "conv_d", x1.dtype,
@@ -407,7 +416,35 @@ def _pack(weight, n, src_strides, dtype):
 
 
 def conv3d(x1, weight, stride=1, padding=0, x2=None):
-    return ConvFn.apply(x1, x2, weight, _t3(stride), _t3(padding))
+    global _last_in_acc
+    _last_in_acc = None
+    out = ConvFn.apply(x1, x2, weight, _t3(stride), _t3(padding))
+    if _last_in_acc is not None:
+        out._ctu_in_acc = _last_in_acc  # instance_norm(out, ...) picks the statistics up instead of re-reading `out`
+        _last_in_acc = None
+    return out
+
+
+# fused InstanceNorm statistics: a small ring of persistent fp64 accumulators (zero when free).  A conv epilogue fills
+# one; instance_norm on that very output finalises it (which zeroes it again).  An accumulator whose output never met
+# an InstanceNorm is re-zeroed when the ring comes round to it.
+FUSE_IN_STATS = True
+_last_in_acc = None
+_IN_ACC_RING = {}
+
+
+def _in_acc_take(device, n):
+    ring = _IN_ACC_RING.get(device)
+    if ring is None or ring[0][0][0].numel() < n:
+        size = max(n, 1 << 13)
+        ring = _IN_ACC_RING[device] = [[[torch.zeros(size, dtype=torch.float64, device=device), False] for _ in range(4)], 0]
+    slots, nxt = ring
+    slot = slots[nxt]
+    ring[1] = (nxt + 1) % len(slots)
+    if slot[1]:
+        slot[0].zero_()
+    slot[1] = True
+    return slot, slot[0]
 
 
 class ConvTransposeFn(torch.autograd.Function):
@@ -514,11 +551,18 @@ class InstanceNormFn(torch.autograd.Function):
         _check_act(x)
         B, C = x.shape[0], x.shape[-1]
         S = x.numel() // (B * C)
-        acc = _in_workspace(x.device, B * C * 2)[0]  # zero on entry, handed back zeroed by ctu_in_stats
         stats = torch.empty((B, C, 2), dtype=torch.float32, device=x.device)
         y = torch.empty_like(x)
         dc = dcode(x.dtype)
-        call("ctu_in_stats", dc, ptr(x), B, S, C, ptr(acc), ptr(stats), stream())
+        fused = getattr(x, "_ctu_in_acc", None)
+        if fused is not None and fused[0][1]:
+            # the producing conv already summed (y, y^2) in its epilogue
+            call("ctu_in_finalize", B, S, C, ptr(fused[1]), ptr(stats), stream())
+            fused[0][1] = False
+            x._ctu_in_acc = None
+        else:
+            acc = _in_workspace(x.device, B * C * 2)[0]  # zero on entry, handed back zeroed by ctu_in_stats
+            call("ctu_in_stats", dc, ptr(x), B, S, C, ptr(acc), ptr(stats), stream())
         call("ctu_in_apply", dc, ptr(x), ptr(stats), ptr(residual), ptr(y), B, S, C, int(act), stream())
         ctx.has_res = residual is not None
         # without a residual sign(y) == sign(xhat): backward recomputes the LeakyReLU mask from x and needs no y

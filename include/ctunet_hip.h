@@ -115,10 +115,13 @@ int ctu_conv_cin1_wgrad(ctu_dtype dtype, const void* x, const void* dy, float* d
  * workgroup, 27 taps served from one staged 6x10x10 halo per 32-channel chunk; weights streamed in MFMA-fragment
  * order).  Forward of ResBlock.conv1/conv2 (hybrid_CTUNet.py:57-74) and Bottleneck.conv2 (resnet.py:98) when the
  * stride is 1, and - with a flipped/transposed panel - their input gradient.  x1/x2: [B][D][H][W][C1|C2] (C multiples
- * of 32); wfrag: panel from ctu_pack_frag; out: [rows][ldc]; columns >= n_split go to out2 (ldc2) when n_split > 0. */
+ * of 32); wfrag: panel from ctu_pack_frag; out: [rows][ldc]; columns >= n_split go to out2 (ldc2) when n_split > 0.
+ * in_acc (optional, fp64 [B][N][2], bf16 / n_split == 0 only): += (sum y, sum y^2) of the fp32 accumulators per batch
+ * item and output channel - the InstanceNorm statistics of the layer that follows (resnet.py:97-99), so that no
+ * separate pass re-reads the output; turn them into (mean, rstd) with ctu_in_finalize. */
 int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, const void* wfrag, void* out, void* out2,
                    int32_t B, int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N, int32_t n_split,
-                   int32_t ldc, int32_t ldc2, ctu_stream_t stream);
+                   int32_t ldc, int32_t ldc2, double* in_acc, ctu_stream_t stream);
 /* Weight gradient of the same convolution with the halo staged once per brick:
  * dw[27][N][C1+C2] += sum_v dy[v][n] * x[v + tap - 1][c]  (fp32 atomics into a zeroed panel). dy: [B][D][H][W][N]. */
 int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void* x1, const void* x2, float* dw, int32_t B,
@@ -145,6 +148,9 @@ int ctu_colsum(ctu_dtype dtype, const void* x, int64_t M, int32_t N, int32_t ld,
  * accumulated in fp64 (no E[x^2]-E[x]^2 cancellation; the deep IN stack amplifies statistic noise ~1000x).  y = act((x-mean)*rstd + residual). */
 int ctu_in_stats(ctu_dtype dtype, const void* x, int32_t B, int64_t S, int32_t C, double* acc_ws, float* stats,
                  ctu_stream_t stream);
+/* (mean, rstd) from UNSHIFTED fp64 sums (sum x, sum x^2) accumulated by a producer (ctu_conv3_halo in_acc); acc is
+ * handed back zeroed. */
+int ctu_in_finalize(int32_t B, int64_t S, int32_t C, double* acc, float* stats, ctu_stream_t stream);
 int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, const void* residual, void* y, int32_t B,
                  int64_t S, int32_t C, int32_t act, ctu_stream_t stream);
 /* backward: g = dy * act'(y) (y may be NULL when no residual was added: then sign(y) == sign(xhat) and the third

@@ -154,6 +154,36 @@ def test_conv3d(ops, dtype, case, halo):
     close(w.grad, wr.grad, dtype, "gw")
 
 
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("case", [(2, 7, 9, 17, 32, 32, 64), (1, 8, 8, 16, 64, 0, 160), (2, 4, 8, 8, 32, 0, 32)])
+def test_conv_instance_norm_fused_statistics(ops, case, fused):
+    """bf16 conv3x3x3 -> InstanceNorm -> LeakyReLU: the statistics come from the conv epilogue (fp32 accumulators summed per
+    brick, ctu_conv3_halo in_acc + ctu_in_finalize) or, with fused=False, from the separate pass over the bf16 output.
+    Both must match the float64 reference; ragged bricks and a partial last n tile included."""
+    B, D, H, W, C1, C2, N = case
+    dtype = torch.bfloat16
+    ops.FUSE_IN_STATS = fused
+    try:
+        x1, x1h = dev(cl(rnd((B, C1, D, H, W), 1)), dtype, True)
+        x2, x2h = dev(cl(rnd((B, C2, D, H, W), 2)), dtype, True) if C2 else (None, None)
+        w, wh = dev(rnd((N, C1 + C2, 3, 3, 3), 3, 1 / math.sqrt((C1 + C2) * 27)), torch.float32, True)
+        conv = ops.conv3d(x1, w, 1, 1, x2)
+        assert (getattr(conv, "_ctu_in_acc", None) is not None) == fused
+        y = ops.instance_norm(conv, None, True)
+        xin = torch.cat((cf(x1h), cf(x2h)), 1) if C2 else cf(x1h)
+        xin.requires_grad_(True)
+        wr = wh.to(dtype).double().requires_grad_(True)
+        ref = F.leaky_relu(F.instance_norm(F.conv3d(xin, wr, padding=1), eps=1e-5), 0.01)
+        close(y, cl(ref), dtype, "y")
+        gy, gyh = dev(cl(rnd(tuple(ref.shape), 4)), dtype)
+        y.backward(gy)
+        ref.backward(cf(gyh))
+        close(w.grad, wr.grad, dtype, "gw")
+        close(x1.grad, cl(xin.grad[:, :C1]), dtype, "gx1")
+    finally:
+        ops.FUSE_IN_STATS = True
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("k", [(2, 2, 2), (2, 2, 1)])
 def test_conv_transpose(ops, dtype, k):
