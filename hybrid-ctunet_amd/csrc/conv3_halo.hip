@@ -30,6 +30,8 @@ struct HaloArgs {
   int B, D, H, W, C1, C2, N, n_split, ldc, ldc2;
   int nbd, nbh, nbw, ntn;  // brick grid, 32-wide n tiles in the whole panel
   double* in_acc;          // optional [B][N][2]: += (sum y, sum y^2) per batch item and channel (InstanceNorm statistics)
+  float* part;             // split over input channels (small volumes): fp32 partial outputs [split][rows][ntn * 32], else NULL
+  int hc_per_split;        // 16-channel half chunks per split (blockIdx.z)
 };
 
 template <typename T, int NT>
@@ -203,8 +205,9 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_dma_kernel(const HaloArgs p
   const int b = t / p.nbd;
   const int d0 = bd * HB_D, h0 = bh * HB_H, w0 = bw * HB_W;
   const int nt0 = blockIdx.y * NT;
-  const int HC = (p.C1 + p.C2) / 16;  // half chunks
-  const int U = HC * 9;               // stages
+  const int hc_b = blockIdx.z * p.hc_per_split;                      // this workgroup's range of 16-channel half chunks
+  const int HC = min((p.C1 + p.C2) / 16, hc_b + p.hc_per_split);    // (exclusive end)
+  const int U = (HC - hc_b) * 9;                                     // stages
   const bf16* x1 = reinterpret_cast<const bf16*>(p.x1);
   const bf16* x2 = reinterpret_cast<const bf16*>(p.x2);
   const bf16* wf = reinterpret_cast<const bf16*>(p.wfrag);
@@ -271,11 +274,11 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_dma_kernel(const HaloArgs p
   int vrow, vcol;
   halo_row_to_hw(r, vrow, vcol);
 
-  issue_halo(0);
-  issue_b(0, 0, 0);
-  issue_b(0, 1, 1);
-  int hc = 0, s = 0, rs = 0;     // stage being computed: half chunk, (td, th) index, ring slot
-  int ihc = 0, is = 2, irs = 2;  // stage being fetched (two ahead)
+  issue_halo(hc_b);
+  issue_b(hc_b, 0, 0);
+  issue_b(hc_b, 1, 1);
+  int hc = hc_b, s = 0, rs = 0;     // stage being computed: half chunk, (td, th) index, ring slot
+  int ihc = hc_b, is = 2, irs = 2;  // stage being fetched (two ahead)
   for (int u = 0; u < U; ++u) {
     // own DMAs of this stage (and, being older, of its halo) have landed; still in flight: the next stage and a
     // halo prefetch issued in one of the last two stages
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_dma_kernel(const HaloArgs p
   }
   wait_vm_then_barrier<0>();  // the tail refetches have landed; LDS is free for the epilogue
 
-  if (p.in_acc) {
+  if (p.in_acc && !p.part) {
     // InstanceNorm statistics of this output, taken from the fp32 accumulators: the separate pass that re-reads the
     // tensor from HBM (in_stats_kernel) disappears.  Lane (r, h) sums its 2 x 16 rows of column r per n tile, the two
     // lane halves are combined by a shuffle, the four waves through LDS, then one fp64 atomic pair per channel and brick.
@@ -383,7 +386,8 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_dma_kernel(const HaloArgs p
           float xv[8];
           load8(&stage[row * STAGE_LD + cv * 8], xv);
           const size_t m = (((size_t)b * p.D + gd) * p.H + gh) * p.W + gw;
-          if (p.n_split > 0 && n >= p.n_split) store8(out2 + m * p.ldc2 + (n - p.n_split), xv);
+          if (p.part) store8(p.part + ((size_t)blockIdx.z * p.B * p.D * p.H * p.W + m) * (p.ntn * 32) + n, xv);
+          else if (p.n_split > 0 && n >= p.n_split) store8(out2 + m * p.ldc2 + (n - p.n_split), xv);
           else store8(out + m * p.ldc + n, xv);
         }
       }
@@ -391,27 +395,101 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_dma_kernel(const HaloArgs p
     }
 }
 
+// Second pass of a channel-split convolution: out[m][n] = bf16(sum_s part[s][m][n]) and, optionally, the InstanceNorm
+// sums of the result.  grid (row chunks, B); block = (N / 8 column groups) x (256 / (N / 8) row lanes).
+__global__ __launch_bounds__(256) void halo_split_finish_kernel(const float* __restrict__ part, bf16* __restrict__ out,
+                                                                double* __restrict__ in_acc, const int nsplit,
+                                                                const int64_t S, const int64_t rows_total, const int N,
+                                                                const int npad, const int ldc, const int64_t rows_per_block) {
+  __shared__ float red[256 * 16];
+  const int ncg = N >> 3;
+  const int tid = threadIdx.x;
+  const int cg = tid % ncg, rl = tid / ncg;
+  const int rlanes = 256 / ncg;
+  const int b = blockIdx.y;
+  const int64_t s_begin = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t s_end = min(S, s_begin + rows_per_block);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  if (rl < rlanes) {
+    for (int64_t sidx = s_begin + rl; sidx < s_end; sidx += rlanes) {
+      const int64_t m = (int64_t)b * S + sidx;
+      float v[8];
+      load8(part + m * npad + cg * 8, v);
+      for (int sp = 1; sp < nsplit; ++sp) {
+        float w[8];
+        load8(part + ((int64_t)sp * rows_total + m) * npad + cg * 8, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += w[e];
+      }
+      store8(out + m * ldc + cg * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+    }
+  }
+  if (!in_acc) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s1[e]; red[tid * 16 + 8 + e] = s2[e]; }
+  __syncthreads();
+  for (int o = tid; o < N * 2; o += 256) {
+    const int c = o >> 1, which = o & 1;
+    const int g = c >> 3, e = c & 7;
+    double a = 0.0;
+    for (int q = 0; q < rlanes; ++q) a += (double)red[(q * ncg + g) * 16 + which * 8 + e];
+    atomicAdd(&in_acc[((size_t)b * N + c) * 2 + which], a);
+  }
+}
+
 template <typename T> struct HaloDma {
-  static bool launch(const HaloArgs&, hipStream_t) { return false; }
+  static bool launch(const HaloArgs&, float*, int64_t, hipStream_t) { return false; }
 };
 template <> struct HaloDma<bf16> {
-  static bool launch(const HaloArgs& p, hipStream_t s) {
+  static bool launch(const HaloArgs& p, float* ws, int64_t ws_floats, hipStream_t s) {
     // 32-bit voxel indices and element offsets inside the kernel
     const int64_t vox = (int64_t)p.B * p.D * p.H * p.W;
     const int cmax = p.C1 > p.C2 ? p.C1 : p.C2;
     if (vox * cmax >= (1ll << 31)) return false;
     const int bricks = p.B * p.nbd * p.nbh * p.nbw;
     const int ntn = p.ntn;
-    if (ntn % 4 == 0) hipLaunchKernelGGL(conv3_halo_dma_kernel<4>, dim3(bricks, ntn / 4), dim3(256), 0, s, p);
-    else if (ntn % 2 == 0) hipLaunchKernelGGL(conv3_halo_dma_kernel<2>, dim3(bricks, ntn / 2), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(conv3_halo_dma_kernel<1>, dim3(bricks, ntn), dim3(256), 0, s, p);
+    const int NT = ntn % 4 == 0 ? 4 : (ntn % 2 == 0 ? 2 : 1);
+    // Small volumes (the 12x12x24 and 6x6x12 stages: 27 and 4 bricks) leave most CUs idle: split the input channels
+    // over workgroups, keep fp32 partial outputs in the workspace and sum them in a second pass (no atomics).
+    const int HCT = (p.C1 + p.C2) / 16;
+    const int blocks = bricks * (ntn / NT);
+    int ksplit = 1;
+    const int64_t rows = (int64_t)p.B * p.D * p.H * p.W;
+    if (ws && blocks < 256 && rows <= 16384 && HCT >= 4 && p.n_split == 0 && p.N % 8 == 0 && p.N <= 2048 && p.ldc % 8 == 0) {
+      ksplit = (512 + blocks - 1) / blocks;
+      if (ksplit > HCT / 2) ksplit = HCT / 2;  // at least two half chunks (18 stages) per workgroup
+      const int64_t cap = ws_floats / (rows * ntn * 32);
+      if (ksplit > cap) ksplit = (int)cap;
+      if (ksplit < 2) ksplit = 1;
+    }
+    HaloArgs q = p;
+    q.hc_per_split = (HCT + ksplit - 1) / ksplit;
+    ksplit = (HCT + q.hc_per_split - 1) / q.hc_per_split;
+    q.part = ksplit > 1 ? ws : nullptr;
+    const dim3 grid(bricks, ntn / NT, ksplit);
+    if (NT == 4) hipLaunchKernelGGL(conv3_halo_dma_kernel<4>, grid, dim3(256), 0, s, q);
+    else if (NT == 2) hipLaunchKernelGGL(conv3_halo_dma_kernel<2>, grid, dim3(256), 0, s, q);
+    else hipLaunchKernelGGL(conv3_halo_dma_kernel<1>, grid, dim3(256), 0, s, q);
+    if (ksplit > 1) {
+      const int64_t S = (int64_t)p.D * p.H * p.W;
+      int64_t chunks = 1024 / p.B;
+      if (chunks < 1) chunks = 1;
+      int64_t rpb = (S + chunks - 1) / chunks;
+      if (rpb < 16) rpb = 16;
+      hipLaunchKernelGGL(halo_split_finish_kernel, dim3((unsigned)((S + rpb - 1) / rpb), p.B), dim3(256), 0, s, ws,
+                         reinterpret_cast<bf16*>(p.out), p.in_acc, ksplit, S, rows, p.N, ntn * 32, p.ldc, rpb);
+    }
     return true;
   }
 };
 
 template <typename T>
-static int launch_halo(const HaloArgs& p, hipStream_t s) {
-  if (HaloDma<T>::launch(p, s)) return ctu_check_launch("conv3_halo");
+static int launch_halo(const HaloArgs& p, float* ws, int64_t ws_floats, hipStream_t s) {
+  if (HaloDma<T>::launch(p, ws, ws_floats, s)) return ctu_check_launch("conv3_halo");
   const int ntn = p.ntn;
   const int bricks = p.B * p.nbd * p.nbh * p.nbw;
   if (ntn >= 4 && ntn % 4 == 0)
@@ -425,7 +503,8 @@ static int launch_halo(const HaloArgs& p, hipStream_t s) {
 
 extern "C" int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, const void* wfrag, void* out, void* out2,
                               int32_t B, int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N,
-                              int32_t n_split, int32_t ldc, int32_t ldc2, double* in_acc, ctu_stream_t stream) {
+                              int32_t n_split, int32_t ldc, int32_t ldc2, double* in_acc, float* ws, int64_t ws_floats,
+                              ctu_stream_t stream) {
   CTU_REQUIRE(x1 && wfrag && out, "conv3_halo: null pointer");
   CTU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3_halo: bad dims");
   CTU_REQUIRE(C1 > 0 && C1 % 32 == 0 && C2 >= 0 && C2 % 32 == 0 && (C2 == 0 || x2), "conv3_halo: C1, C2 must be multiples of 32");
@@ -435,13 +514,17 @@ extern "C" int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, c
   p.x1 = x1; p.x2 = x2; p.wfrag = wfrag; p.out = out; p.out2 = out2;
   p.B = B; p.D = D; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.N = N; p.n_split = n_split; p.ldc = ldc; p.ldc2 = ldc2;
   p.in_acc = in_acc;
+  p.part = nullptr;
+  p.hc_per_split = (C1 + C2) / 16;
+  CTU_REQUIRE(ws_floats >= 0 && (ws_floats == 0 || ws), "conv3_halo: bad workspace");
   CTU_REQUIRE(!in_acc || (dtype == CTU_BF16 && n_split == 0 &&
                           (int64_t)B * D * H * W * (C1 > C2 ? C1 : C2) < (1ll << 31)),
               "conv3_halo: fused InstanceNorm statistics need the bf16 LDS-DMA kernel (no split, < 2^31 elements)");
   p.nbd = (D + HB_D - 1) / HB_D; p.nbh = (H + HB_H - 1) / HB_H; p.nbw = (W + HB_W - 1) / HB_W;
   p.ntn = (N + 31) / 32;
   CTU_REQUIRE((int64_t)B * p.nbd * p.nbh * p.nbw < (1ll << 31), "conv3_halo: too many bricks");
-  CTU_DISPATCH(dtype, return launch_halo<float>(p, (hipStream_t)stream), return launch_halo<bf16>(p, (hipStream_t)stream));
+  CTU_DISPATCH(dtype, return launch_halo<float>(p, ws, ws_floats, (hipStream_t)stream),
+               return launch_halo<bf16>(p, ws, ws_floats, (hipStream_t)stream));
 }
 
 // ---------------------------------------------------------------------------------------------------------
