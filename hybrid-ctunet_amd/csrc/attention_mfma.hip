@@ -204,7 +204,11 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(const T* __restric
   __shared__ __attribute__((aligned(16))) T Ks[NP * LD];
   __shared__ __attribute__((aligned(16))) T Vs[NP * LD];
   __shared__ float tbl[1331];
-  __shared__ float dtbl[1331];
+  // bias-gradient table, one private copy per wave, updated with PLAIN read-add-write: for a fixed key the map
+  // query -> relative-position index is injective, so the 32 lanes of a half never collide and the two halves go one
+  // after the other.  (ds_add_f32 retires about one lane per clock: 16 of them per lane and tile pair made this
+  // kernel 4x slower than its key/value twin.)
+  __shared__ float dtbl[4][1332];  // [1331] = dump slot of masked (out-of-range) pairs
   __shared__ int krel[NP];
   const int heads = c.g.heads;
   const int grp = blockIdx.x / heads, head = blockIdx.x % heads;
@@ -215,7 +219,10 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(const T* __restric
   const bool has_bias = bias_table != nullptr;
   const int ntbl = c.relm * c.relm * c.relm;
   if (has_bias) {
-    for (int i = threadIdx.x; i < ntbl; i += 256) { tbl[i] = bias_table[(size_t)i * heads + head]; dtbl[i] = 0.f; }
+    for (int i = threadIdx.x; i < ntbl; i += 256) {
+      tbl[i] = bias_table[(size_t)i * heads + head];
+      dtbl[0][i] = 0.f; dtbl[1][i] = 0.f; dtbl[2][i] = 0.f; dtbl[3][i] = 0.f;
+    }
     for (int i = threadIdx.x; i < NP; i += 256) krel[i] = relcode(c, i < c.ntok ? i : 0);
   }
   __syncthreads();
@@ -256,6 +263,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(const T* __restric
         Mma<T>::mma(Mma<T>::load(&Vs[(kt * 32 + r) * LD + ks * 16 + 8 * h]), fg[ks], dp);
       }
       float ds[16];
+      int bis[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int key = kt * 32 + acc_row(e, h);
@@ -264,8 +272,19 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(const T* __restric
         if (has_bias) { bi = relq - krel[key]; v += tbl[bi]; }
         const bool ok = qok && key < c.ntok;
         const float pv = ok ? __expf(v - lq) : 0.f;
-        ds[e] = pv * (dp[e] - delta);
-        if (has_bias && ok) atomicAdd(&dtbl[bi], ds[e]);
+        ds[e] = pv * (dp[e] - delta);  // 0 for masked pairs: adding it below is harmless
+        bis[e] = ok ? bi : 1331;
+      }
+      if (has_bias) {
+        float* mytbl = dtbl[wave];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          if (h == half) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mytbl[bis[e]] += ds[e];
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
       }
 #pragma unroll
       for (int sh = 0; sh < 2; ++sh) {
@@ -290,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(const T* __restric
   if (has_bias) {
     __syncthreads();
     for (int i = threadIdx.x; i < ntbl; i += 256) {
-      const float v = dtbl[i];
+      const float v = (dtbl[0][i] + dtbl[1][i]) + (dtbl[2][i] + dtbl[3][i]);
       if (v != 0.f) atomicAdd(&dbias[(size_t)i * heads + head], v);
     }
   }

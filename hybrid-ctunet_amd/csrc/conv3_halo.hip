@@ -300,6 +300,8 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_dma_kernel(const HaloArgs p
       const int R = (wave + td) * HALO_H + 4 * i + vrow + th;
       aoff[i] = ((R * HALO_W + vcol) * 2 + (h ^ ((R >> 1) & 1))) * 16;
     }
+    // (measured: requesting the fragments of all three taps up front + s_setprio around the 6 NT MFMAs is 5-10 % SLOWER
+    // than letting hipcc interleave reads and MFMAs tap by tap - the second wave of the SIMD hides the read latency)
 #pragma unroll
     for (int tw = 0; tw < 3; ++tw) {
       bf16x8 fa[2], fb[NT];
