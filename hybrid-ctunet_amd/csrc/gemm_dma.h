@@ -12,6 +12,8 @@ struct GemmNtArgs {
   int M, N, K, C1, C2;
   int splitk;      // in: requested split; out: the split used
   float* ws;       // fp32 [M][N], zeroed (split-K only)
+  double* in_acc;  // optional [M / in_rows][N][2] += (sum, sum of squares) of the output columns per batch item
+  int in_rows;     // rows per batch item (a multiple of 128: no tile straddles two items)
   int tiles_m, tiles_n, ksteps, ks_per_split, nwork;  // filled by the launcher
 };
 

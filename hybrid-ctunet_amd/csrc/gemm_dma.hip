@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) voi
   constexpr int EPI_BYTES = 4 * 16 * EPI_LD * 4;
   constexpr int IPW = APW + BPW;   // DMA instructions per wave and stage
   static_assert((R - 2) * IPW <= 8, "counted vmcnt switch covers 0..8");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[R * STAGE + EPI_BYTES];
+  constexpr int RED_BYTES = 4 * WN * 2 * 4;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[R * STAGE + EPI_BYTES + RED_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -219,6 +220,39 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) voi
     }
 
     if (last) {
+      if (p.in_acc) {
+        // InstanceNorm statistics of the output (the 1x1x1 convs of the ResNet bottlenecks feed an InstanceNorm): column
+        // sums of the fp32 accumulators - lane (r, h) owns column r of each n tile -> the two lane halves by shuffle,
+        // the two waves that share the columns through LDS, one fp64 atomic pair per column and tile.  The host
+        // guarantees that a tile never straddles two batch items and that all its rows exist.
+        float* red = reinterpret_cast<float*>(smem + R * STAGE + EPI_BYTES);  // [4 waves][WN][2]
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { const float v = acc[i][j][e]; s1 += v; s2 += v * v; }
+          s1 += __shfl_xor(s1, 32, 64);
+          s2 += __shfl_xor(s2, 32, 64);
+          if (h == 0) {
+            red[(wave * WN + j * 32 + r) * 2] = s1;
+            red[(wave * WN + j * 32 + r) * 2 + 1] = s2;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (vmcnt untouched: the next stages stay in flight)
+        if (tid < BN) {
+          const int wq = tid / WN, col = tid - wq * WN;  // waves wq (wm = 0) and wq + 2 (wm = 1) hold these columns
+          const int n = cur.n0 + tid;
+          if (n < p.N) {
+            const float t1 = red[(wq * WN + col) * 2] + red[((wq + 2) * WN + col) * 2];
+            const float t2 = red[(wq * WN + col) * 2 + 1] + red[((wq + 2) * WN + col) * 2 + 1];
+            const int b = cur.m0 / p.in_rows;
+            atomicAdd(&p.in_acc[((size_t)b * p.N + n) * 2], (double)t1);
+            atomicAdd(&p.in_acc[((size_t)b * p.N + n) * 2 + 1], (double)t2);
+          }
+        }
+      }
       // epilogue through a wave-private 16 x 32 fp32 patch (outside the DMA ring: the next tile is already in flight)
 #pragma unroll
       for (int i = 0; i < MI; ++i)

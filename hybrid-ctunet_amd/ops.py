@@ -163,9 +163,11 @@ def _splitk_workspace(device, n):
 
 
 def _epi(ldc, bias=None, residual=None, act=0, out2=None, n_split=0, ldc2=0, scatter=None, splitk_ws=None,
-         splitk=1, w_kn=0) -> Epilogue:
+         splitk=1, w_kn=0, in_acc=None, in_rows=0) -> Epilogue:
     e = Epilogue()
     e.w_kn = w_kn
+    e.in_acc = ptr(in_acc)
+    e.in_rows = in_rows
     e.splitk = splitk if splitk_ws is not None else 1
     e.splitk_ws = ptr(splitk_ws)
     e.bias = ptr(bias)
@@ -214,12 +216,13 @@ def _igemm_tn(p, ldp, q1, q2, dw, g: Geom, bias_grad=None):
          stream())
 
 
-def _plain_gemm(x, w, out, M, K, N, bias=None, residual=None, act=0, w_kn=0):
+def _plain_gemm(x, w, out, M, K, N, bias=None, residual=None, act=0, w_kn=0, in_acc=None, in_rows=0):
     """out[M,N] = act(x[M,K] @ w[N,K]^T + bias) + residual, with split-K when there are few tiles and a long K."""
-    sk = _splitk_for(M, N, K, dma=x.dtype == torch.bfloat16 and K % 64 == 0)
+    sk = 1 if in_acc is not None else _splitk_for(M, N, K, dma=x.dtype == torch.bfloat16 and K % 64 == 0)
     ws = _splitk_workspace(x.device, M * N) if sk > 1 else None
     _igemm_nt(x, None, w, out, _plain_geom(M, K, N),
-              _epi(N, bias=bias, residual=residual, act=act, splitk_ws=ws, splitk=sk, w_kn=w_kn))
+              _epi(N, bias=bias, residual=residual, act=act, splitk_ws=ws, splitk=sk, w_kn=w_kn, in_acc=in_acc,
+                   in_rows=in_rows))
 
 
 USE_W_KN = True  # tests clear this together with the "generic_gemm" hook (the generic kernels need W transposed)
@@ -243,10 +246,16 @@ class LinearFn(torch.autograd.Function):
     1x1x1 nn.Conv3d at resnet.py:96,100 and hybrid_CTUNet.py:75-83."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, act: int):
+    def forward(ctx, x, weight, bias, residual, act: int, in_stats: bool = False):
         _check_act(x)
         N, K = weight.shape[0], weight[0].numel()
         M = x.numel() // K
+        acc, rows = None, 0
+        if (in_stats and FUSE_IN_STATS and USE_W_KN and x.dtype == torch.bfloat16 and K % 64 == 0 and x.dim() >= 3
+                and bias is None and residual is None and act == 0):
+            rows = M // x.shape[0]  # rows per batch item: a 1x1x1 conv whose output feeds an InstanceNorm
+            if rows % 128 == 0 and rows * x.shape[0] == M:
+                acc = _in_acc_take(x.device, x.shape[0] * N * 2)
         w2 = weight.reshape(N, K)
         wf = _linear_weight(weight, w2, x.dtype)
         pre = None
@@ -259,7 +268,11 @@ class LinearFn(torch.autograd.Function):
             if residual is not None:
                 call("ctu_add", dcode(x.dtype), ptr(out), ptr(residual), ptr(out), out.numel(), stream())
         else:
-            _plain_gemm(x, wf, out, M, K, N, bias=bias, residual=residual, act=act)
+            _plain_gemm(x, wf, out, M, K, N, bias=bias, residual=residual, act=act,
+                        in_acc=acc[1] if acc is not None else None, in_rows=rows)
+            if acc is not None:
+                global _last_in_acc
+                _last_in_acc = acc
         ctx.save_for_backward(x, weight, pre, bias)
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
@@ -302,11 +315,19 @@ class LinearFn(torch.autograd.Function):
             gw_done()
         if gb_done is not None:
             gb_done()
-        return gx, gw, gb, gres, None
+        return gx, gw, gb, gres, None, None
 
 
-def linear(x, weight, bias=None, residual=None, act: int = 0):
-    return LinearFn.apply(x, weight, bias, residual, act)
+def linear(x, weight, bias=None, residual=None, act: int = 0, in_stats: bool = False):
+    """in_stats=True: the caller will feed the result to instance_norm (a 1x1x1 conv of a ResNet bottleneck): its
+    statistics are then summed in the GEMM epilogue when the shape allows it."""
+    global _last_in_acc
+    _last_in_acc = None
+    out = LinearFn.apply(x, weight, bias, residual, act, in_stats)
+    if _last_in_acc is not None:
+        out._ctu_in_acc = _last_in_acc
+        _last_in_acc = None
+    return out
 
 
 class ConvFn(torch.autograd.Function):

@@ -84,6 +84,12 @@ typedef struct ctu_epilogue {
    * Only with dtype bf16, K % 64 == 0 and N % 8 == 0 (the LDS-DMA GEMM); anything else is CTU_ERR_ARG. */
   int32_t w_kn;
   float* splitk_ws;
+  /* fused InstanceNorm statistics (plain bf16 LDS-DMA GEMM without split-K only, else CTU_ERR_ARG): in_acc fp64
+   * [M / in_rows][N][2] += (sum, sum of squares) of the fp32 results per batch item of in_rows rows (in_rows % 128 == 0,
+   * M % in_rows == 0) and output column; finish with ctu_in_finalize. */
+  double* in_acc;
+  int32_t in_rows;
+  int32_t reserved_;
 } ctu_epilogue;
 
 /* K1/K3/K5/K2/K4 forward and data-gradient:  out[m][n] = sum_tap sum_c A[gather(m,tap)][c] * W[tap][n][c]

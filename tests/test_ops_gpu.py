@@ -184,6 +184,28 @@ def test_conv_instance_norm_fused_statistics(ops, case, fused):
         ops.FUSE_IN_STATS = True
 
 
+@pytest.mark.parametrize("case", [(2, 4, 8, 8, 64, 256), (2, 8, 8, 8, 128, 72), (1, 2, 8, 8, 192, 64)])
+def test_conv1x1_instance_norm_fused_statistics(ops, case):
+    """bf16 1x1x1 conv (plain GEMM) -> InstanceNorm: statistics summed in the LDS-DMA GEMM epilogue (ctu_epilogue.in_acc)
+    vs the float64 reference; rows per batch item are multiples of 128, N with a partial last tile included."""
+    B, D, H, W, K, N = case
+    dtype = torch.bfloat16
+    x, xh = dev(cl(rnd((B, K, D, H, W), 1)) + 0.25, dtype, True)
+    w, wh = dev(rnd((N, K, 1, 1, 1), 2, 1 / math.sqrt(K)), torch.float32, True)
+    conv = ops.linear(x, w, in_stats=True)
+    assert getattr(conv, "_ctu_in_acc", None) is not None
+    y = ops.instance_norm(conv, None, False)  # no LeakyReLU: its mask flips on near-zero values would dominate gx
+    xr = cf(xh).requires_grad_(True)
+    wr = wh.to(dtype).double().requires_grad_(True)
+    ref = F.instance_norm(F.conv3d(xr, wr), eps=1e-5)
+    close(y, cl(ref), dtype, "y")
+    gy, gyh = dev(cl(rnd(tuple(ref.shape), 3)), dtype)
+    y.backward(gy)
+    ref.backward(cf(gyh))
+    close(x.grad, cl(xr.grad), dtype, "gx")
+    close(w.grad, wr.grad, dtype, "gw")
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("k", [(2, 2, 2), (2, 2, 1)])
 def test_conv_transpose(ops, dtype, k):
