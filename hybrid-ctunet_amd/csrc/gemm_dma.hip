@@ -178,6 +178,39 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) voi
   bf16* out = reinterpret_cast<bf16*>(p.out);
 
   if (vid >= p.nwork) return;
+  // running InstanceNorm sums of this workgroup (in_acc): lane (r, h) owns column r of each of its n tiles
+  float rs1[NJ], rs2[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) { rs1[j] = 0.f; rs2[j] = 0.f; }
+  int stat_b = 0, stat_n0 = 0;
+  bool stat_live = false;
+  auto stat_flush = [&]() {
+    // lane halves by shuffle, the two waves that share the columns through LDS, one fp64 atomic pair per column.
+    // The host guarantees that a tile never straddles two batch items and that all its rows exist.
+    float* red = reinterpret_cast<float*>(smem + R * STAGE + EPI_BYTES);  // [4 waves][WN][2]
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float s1 = rs1[j] + __shfl_xor(rs1[j], 32, 64);
+      const float s2 = rs2[j] + __shfl_xor(rs2[j], 32, 64);
+      if (h == 0) {
+        red[(wave * WN + j * 32 + r) * 2] = s1;
+        red[(wave * WN + j * 32 + r) * 2 + 1] = s2;
+      }
+      rs1[j] = 0.f; rs2[j] = 0.f;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (vmcnt untouched: the next stages stay in flight)
+    if (tid < BN) {
+      const int wq = tid / WN, col = tid - wq * WN;  // waves wq (wm = 0) and wq + 2 (wm = 1) hold these columns
+      const int n = stat_n0 + tid;
+      if (n < p.N) {
+        const float t1 = red[(wq * WN + col) * 2] + red[((wq + 2) * WN + col) * 2];
+        const float t2 = red[(wq * WN + col) * 2 + 1] + red[((wq + 2) * WN + col) * 2 + 1];
+        atomicAdd(&p.in_acc[((size_t)stat_b * p.N + n) * 2], (double)t1);
+        atomicAdd(&p.in_acc[((size_t)stat_b * p.N + n) * 2 + 1], (double)t2);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // red may be rewritten by the next flush
+  };
   // two cursors over the flat sequence of (work item, k step) stages of this workgroup: issue runs R - 1 ahead of compute
   int wi = vid, iwi = vid;
   WorkItem cur = decode(wi), icur = cur;
@@ -222,36 +255,19 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) voi
     if (last) {
       if (p.in_acc) {
         // InstanceNorm statistics of the output (the 1x1x1 convs of the ResNet bottlenecks feed an InstanceNorm): column
-        // sums of the fp32 accumulators - lane (r, h) owns column r of each n tile -> the two lane halves by shuffle,
-        // the two waves that share the columns through LDS, one fp64 atomic pair per column and tile.  The host
-        // guarantees that a tile never straddles two batch items and that all its rows exist.
-        float* red = reinterpret_cast<float*>(smem + R * STAGE + EPI_BYTES);  // [4 waves][WN][2]
+        // sums of the fp32 accumulators, kept in registers ACROSS the tiles of this persistent workgroup while they
+        // belong to the same (batch item, n tile) - with gridDim a multiple of tiles_n that is all of them but one
+        // switch per batch item - and flushed as one fp64 atomic pair per column (stat_flush).  Per address that is
+        // ~one atomic per workgroup instead of one per tile (3456 same-address atomics made a 29 us GEMM 46 us).
+        const int sb = cur.m0 / p.in_rows;
+        if (stat_live && (sb != stat_b || cur.n0 != stat_n0)) stat_flush();
+        stat_b = sb; stat_n0 = cur.n0; stat_live = true;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          float s1 = 0.f, s2 = 0.f;
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { const float v = acc[i][j][e]; s1 += v; s2 += v * v; }
-          s1 += __shfl_xor(s1, 32, 64);
-          s2 += __shfl_xor(s2, 32, 64);
-          if (h == 0) {
-            red[(wave * WN + j * 32 + r) * 2] = s1;
-            red[(wave * WN + j * 32 + r) * 2 + 1] = s2;
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (vmcnt untouched: the next stages stay in flight)
-        if (tid < BN) {
-          const int wq = tid / WN, col = tid - wq * WN;  // waves wq (wm = 0) and wq + 2 (wm = 1) hold these columns
-          const int n = cur.n0 + tid;
-          if (n < p.N) {
-            const float t1 = red[(wq * WN + col) * 2] + red[((wq + 2) * WN + col) * 2];
-            const float t2 = red[(wq * WN + col) * 2 + 1] + red[((wq + 2) * WN + col) * 2 + 1];
-            const int b = cur.m0 / p.in_rows;
-            atomicAdd(&p.in_acc[((size_t)b * p.N + n) * 2], (double)t1);
-            atomicAdd(&p.in_acc[((size_t)b * p.N + n) * 2 + 1], (double)t2);
-          }
-        }
+            for (int e = 0; e < 16; ++e) { const float v = acc[i][j][e]; rs1[j] += v; rs2[j] += v * v; }
       }
       // epilogue through a wave-private 16 x 32 fp32 patch (outside the DMA ring: the next tile is already in flight)
 #pragma unroll
@@ -300,6 +316,7 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) voi
     }
     st = st + 1 == R ? 0 : st + 1;
   }
+  if (stat_live) stat_flush();
 }
 
 int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {

@@ -71,7 +71,7 @@ class ConvLayer(nn.Module):
         else:
             self.conv = nn.Conv3d(in_channels, out_channels, k, stride=s, padding=p, bias=bias)
 
-    def forward(self, x, x2=None):
+    def forward(self, x, x2=None, grad_stash=None):
         w = self.conv.weight
         if self.is_transposed:
             assert x2 is None
@@ -80,7 +80,9 @@ class ConvLayer(nn.Module):
             assert x2 is None
             return ops.conv3d_cin1(x, w, self.stride, self.padding)
         if x2 is None and self.kernel_size == (1, 1, 1) and self.stride == (1, 1, 1):
-            return ops.linear(x, w, in_stats=True)  # every 1x1x1 ConvLayer of these networks feeds an InstanceNorm
+            # every 1x1x1 ConvLayer of these networks feeds an InstanceNorm
+            return ops.linear(x, w, in_stats=True, grad_stash=grad_stash)
+        assert grad_stash is None
         return ops.conv3d(x, w, self.stride, self.padding, x2)
 
 
@@ -126,10 +128,15 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = ops.instance_norm(self.conv1(x), None, True)
+        stash = [] if (self.downsample is None and x.requires_grad and torch.is_grad_enabled()) else None
+        out = ops.instance_norm(self.conv1(x, grad_stash=stash), None, True)
         out = ops.instance_norm(self.conv2(out), None, True)
         out = self.conv3(out)
-        residual = x if self.downsample is None else self.downsample(x)
+        if self.downsample is not None:
+            residual = self.downsample(x)
+        else:
+            # identity shortcut: its gradient is folded into conv1's data-gradient GEMM (ops.GradStash)
+            residual = ops.GradStash.apply(x, stash) if stash is not None else x
         return ops.instance_norm(out, residual, True)  # gn3 -> += residual -> LeakyReLU (resnet.py:118-124)
 
 

@@ -246,8 +246,9 @@ class LinearFn(torch.autograd.Function):
     1x1x1 nn.Conv3d at resnet.py:96,100 and hybrid_CTUNet.py:75-83."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, act: int, in_stats: bool = False):
+    def forward(ctx, x, weight, bias, residual, act: int, in_stats: bool = False, grad_stash=None):
         _check_act(x)
+        ctx.grad_stash = grad_stash
         N, K = weight.shape[0], weight[0].numel()
         M = x.numel() // K
         acc, rows = None, 0
@@ -293,12 +294,17 @@ class LinearFn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
+            # gradient that reached x through another branch (GradStash): added in this GEMM's epilogue instead of by
+            # a separate autograd accumulation pass over three tensors
+            extra = ctx.grad_stash.pop() if ctx.grad_stash else None
+            if extra is not None and (extra.shape != x.shape or extra.dtype != x.dtype or not extra.is_contiguous()):
+                extra = extra.to(x.dtype).contiguous().view_as(x)
             if USE_W_KN and x.dtype == torch.bfloat16 and N % 64 == 0 and K % 8 == 0:
                 # dX = dY @ W: the LDS-DMA GEMM reads the forward weight [N][K] reduction-major, no transposed copy
-                _plain_gemm(g, _linear_weight(weight, weight.reshape(N, K), x.dtype), gx, M, N, K, w_kn=1)
+                _plain_gemm(g, _linear_weight(weight, weight.reshape(N, K), x.dtype), gx, M, N, K, w_kn=1, residual=extra)
             else:
                 wd = _packed(weight, "lin_d", x.dtype, lambda: weight.detach().reshape(N, K).t().to(x.dtype).contiguous())
-                _plain_gemm(g, wd, gx, M, N, K)
+                _plain_gemm(g, wd, gx, M, N, K, residual=extra)
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         # accumulate straight into persistent .grad storage when the harness registered it (see register_grad_sink)
         gw_buf, gw_done = _direct_grad(weight) if ctx.needs_input_grad[1] else (None, None)
@@ -315,15 +321,32 @@ class LinearFn(torch.autograd.Function):
             gw_done()
         if gb_done is not None:
             gb_done()
-        return gx, gw, gb, gres, None, None
+        return gx, gw, gb, gres, None, None, None
 
 
-def linear(x, weight, bias=None, residual=None, act: int = 0, in_stats: bool = False):
+class GradStash(torch.autograd.Function):
+    """Identity whose backward parks the incoming gradient in `slot` (a list) instead of returning it.  Used on the
+    residual branch of a bottleneck: the branch's gradient w.r.t. the block input is then added inside the data-gradient
+    GEMM of the block's first conv (LinearFn, grad_stash=slot), which autograd runs later, rather than by a separate
+    elementwise pass.  The node must be created AFTER that conv's node so that it runs first in backward."""
+
+    @staticmethod
+    def forward(ctx, x, slot):
+        ctx.slot = slot
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.slot.append(g)
+        return None, None
+
+
+def linear(x, weight, bias=None, residual=None, act: int = 0, in_stats: bool = False, grad_stash=None):
     """in_stats=True: the caller will feed the result to instance_norm (a 1x1x1 conv of a ResNet bottleneck): its
     statistics are then summed in the GEMM epilogue when the shape allows it."""
     global _last_in_acc
     _last_in_acc = None
-    out = LinearFn.apply(x, weight, bias, residual, act, in_stats)
+    out = LinearFn.apply(x, weight, bias, residual, act, in_stats, grad_stash)
     if _last_in_acc is not None:
         out._ctu_in_acc = _last_in_acc
         _last_in_acc = None
