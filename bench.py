@@ -90,6 +90,25 @@ class KernelTimer:
         return out
 
 
+def pmc_traffic(entry_point):
+    """HBM bytes per launch of the dominant entry point's kernels, from the committed rocprofv3 PMC passes over this very
+    command (profiles/r01_pmc_hbm_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate passes, per the guide's gfx950
+    correction).  Counters cannot be read from inside the process, so this is the last profiled value, not a live one;
+    None when the file is absent or the model is not the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    key = {"ctu_conv3_halo": "conv3_halo_dma_kernel", "ctu_conv3_halo_wgrad": "conv3_halo_wgrad_dma_kernel",
+           "ctu_igemm_nt": "gemm_nt_dma_kernel", "ctu_igemm_tn": "gemm_tn_dma_kernel"}.get(entry_point)
+    if key is None or not os.path.exists(path):
+        return None
+    ks = json.load(open(path))["kernels"]
+    n = b = 0.0
+    for name, v in ks.items():
+        if key in name:
+            n += v["launches_per_step"]
+            b += v["launches_per_step"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
+    return round(b / n) if n else None
+
+
 def cpu_baseline(model_name, threads):
     """Oracle on the host cores: one 96^3 volume, fwd + loss + bwd + AdamW, fp32."""
     from oracle import ctunet_oracle as O
@@ -198,7 +217,7 @@ def main():
         tot = {k: round(v["ms"] / 2, 3) for k, v in s.items()}
         ach = s[dom]["flops"] / (s[dom]["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": dom,
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom), "kernel": dom,
                     "launches_per_step": s[dom]["launches"] // 2,
                     "avg_launch_ms": round(s[dom]["ms"] / s[dom]["launches"], 4),
                     "igemm_ms_per_step": tot,

@@ -624,8 +624,8 @@ extern "C" int ctu_cast(const void* src, ctu_dtype sd, void* dst, ctu_dtype dd, 
 }
 
 // dst[i0*d0+i1*d1+i2*d2] (=|+=) src[i0*s0+i1*s1+i2*s2]; thread index runs over (i0,i1,i2) with i2 fastest
-template <typename TD, bool ACC>
-__global__ __launch_bounds__(256) void permute3_kernel(const float* __restrict__ src, TD* __restrict__ dst,
+template <typename TD, bool ACC, bool CLEAR = false>
+__global__ __launch_bounds__(256) void permute3_kernel(float* __restrict__ src, TD* __restrict__ dst,
                                                        const int64_t n0, const int64_t n1, const int64_t n2,
                                                        const int64_t s0, const int64_t s1, const int64_t s2,
                                                        const int64_t d0, const int64_t d1, const int64_t d2) {
@@ -635,19 +635,23 @@ __global__ __launch_bounds__(256) void permute3_kernel(const float* __restrict__
     const int64_t t = i / n2;
     const int64_t i1 = t % n1, i0 = t / n1;
     const float v = src[i0 * s0 + i1 * s1 + i2 * s2];
+    if (CLEAR) src[i0 * s0 + i1 * s1 + i2 * s2] = 0.f;  // hand a scratch panel back zeroed (each element is read once)
     TD* p = dst + i0 * d0 + i1 * d1 + i2 * d2;
     if (ACC) *p = (TD)((float)*p + v);
     else *p = (TD)v;
   }
 }
-extern "C" int ctu_permute3(const float* src, void* dst, ctu_dtype dd, int64_t n0, int64_t n1, int64_t n2, int64_t s0,
+extern "C" int ctu_permute3(float* src, void* dst, ctu_dtype dd, int64_t n0, int64_t n1, int64_t n2, int64_t s0,
                             int64_t s1, int64_t s2, int64_t d0, int64_t d1, int64_t d2, int32_t accumulate,
                             ctu_stream_t stream) {
   CTU_REQUIRE(src && dst && n0 > 0 && n1 > 0 && n2 > 0, "permute3: bad args");
   CTU_REQUIRE(!accumulate || dd == CTU_F32, "permute3: accumulate needs an fp32 destination");
   hipStream_t s = (hipStream_t)stream;
   const unsigned grid = grid_for(n0 * n1 * n2, 256);
-  if (dd == CTU_F32 && accumulate)
+  if (dd == CTU_F32 && accumulate == 2)
+    hipLaunchKernelGGL((permute3_kernel<float, true, true>), dim3(grid), dim3(256), 0, s, src, (float*)dst, n0, n1, n2, s0,
+                       s1, s2, d0, d1, d2);
+  else if (dd == CTU_F32 && accumulate)
     hipLaunchKernelGGL((permute3_kernel<float, true>), dim3(grid), dim3(256), 0, s, src, (float*)dst, n0, n1, n2, s0, s1,
                        s2, d0, d1, d2);
   else if (dd == CTU_F32)

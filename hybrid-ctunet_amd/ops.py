@@ -121,7 +121,7 @@ def permute3(src: torch.Tensor, dst: torch.Tensor, n, s, d, accumulate=False):
     """dst[i0*d0+i1*d1+i2*d2] (+)= src[i0*s0+i1*s1+i2*s2]; src fp32."""
     assert src.dtype == torch.float32
     call("ctu_permute3", ptr(src), ptr(dst), dcode(dst.dtype), n[0], n[1], n[2], s[0], s[1], s[2], d[0], d[1], d[2],
-         1 if accumulate else 0, stream())
+         int(accumulate), stream())
 
 
 def _t3(v) -> Tuple[int, int, int]:
@@ -420,7 +420,13 @@ class ConvFn(torch.autograd.Function):
                 gd = _geom(B, dout, (D, H, W), N, 0, K, k, stride, padding, 1)
                 _igemm_nt(gy, None, wd, g1, gd, _epi(C1, out2=g2, n_split=C1 if x2 is not None else 0, ldc2=C2))
         if ctx.needs_input_grad[2]:
-            panel = torch.zeros((taps, N, K), dtype=torch.float32, device=x1.device)
+            gw_buf, gw_done = _direct_grad(weight) if taps > 1 else (None, None)
+            if gw_buf is not None:
+                # persistent zeroed scratch panel: the wgrad kernel accumulates into it, permute3 adds it into the
+                # parameter's gradient storage in the parameter's layout and hands the panel back zeroed
+                panel = _panel_scratch(x1.device, taps * N * K).view(taps, N, K)
+            else:
+                panel = torch.zeros((taps, N, K), dtype=torch.float32, device=x1.device)
             if _halo_ok(k, stride, padding) and C1 % 32 == 0 and C2 % 32 == 0:
                 call("ctu_conv3_halo_wgrad", dcode(x1.dtype), ptr(gy), ptr(x1), ptr(x2), ptr(panel), B, D, H, W, C1, C2,
                      N, stream())
@@ -429,10 +435,25 @@ class ConvFn(torch.autograd.Function):
                 _igemm_tn(gy, N, x1, x2, panel, gq)
             if taps == 1:
                 gw = panel.view(weight.shape)
+            elif gw_buf is not None:
+                permute3(panel, gw_buf, (N, K, taps), (K, 1, N * K), (K * taps, taps, 1), accumulate=2)
+                gw_done()
             else:
                 gw = torch.empty(weight.shape, dtype=torch.float32, device=x1.device)
                 permute3(panel, gw, (N, K, taps), (K, 1, N * K), (K * taps, taps, 1))
         return g1, g2, gw, None, None
+
+
+_PANEL_SCRATCH = {}
+
+
+def _panel_scratch(device, n):
+    """Persistent fp32 scratch for multi-tap weight-gradient panels; zero between uses (permute3 accumulate=2 clears
+    what it read), single compute stream."""
+    t = _PANEL_SCRATCH.get(device)
+    if t is None or t.numel() < n:
+        t = _PANEL_SCRATCH[device] = torch.zeros(max(n, 27 * 512 * 512), dtype=torch.float32, device=device)
+    return t[:n]
 
 
 USE_HALO_CONV = True  # tests flip this to run the generic implicit GEMM on the same shapes

@@ -142,8 +142,10 @@ int ctu_pack_frag(const float* src, void* dst, ctu_dtype dst_dtype, int32_t N, i
 
 /* Strided 3-index permute + cast: dst[i0*d0 + i1*d1 + i2*d2] = (dst_dtype) src[i0*s0 + i1*s1 + i2*s2].
  * src is fp32 (master weights / packed fp32 gradients).  Used to pack weights into [taps][N][K] panels and
- * to unpack panel gradients back into the nn.Module's parameter layout (accumulate=1 adds into dst, fp32). */
-int ctu_permute3(const float* src, void* dst, ctu_dtype dst_dtype, int64_t n0, int64_t n1, int64_t n2,
+ * to unpack panel gradients back into the nn.Module's parameter layout (accumulate=1 adds into dst, fp32;
+ * accumulate=2 additionally writes zeros back to every src element it read: a persistent scratch panel is handed
+ * back clean, no memset launch). */
+int ctu_permute3(float* src, void* dst, ctu_dtype dst_dtype, int64_t n0, int64_t n1, int64_t n2,
                  int64_t s0, int64_t s1, int64_t s2, int64_t d0, int64_t d1, int64_t d2, int32_t accumulate,
                  ctu_stream_t stream);
 /* column sums (bias gradients): out[n] += sum_m x[m][n], x is [M][ld] */

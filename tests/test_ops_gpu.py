@@ -466,6 +466,22 @@ def test_direct_gradient_sink_matches_autograd_path(ops):
     assert fp.touched == [True, True, True, True, True, False]
     ops.clear_grad_sinks()
 
+    # 27-tap conv weights: wgrad panel in the persistent scratch -> permute3(accumulate=2) into the flat gradient
+    wc = torch.randn(64, 32, 3, 3, 3) * 0.05
+    xc = torch.randn(2, 5, 9, 8, 32).cuda()
+    gc = torch.randn(2, 5, 9, 8, 64).cuda()
+    for dtype in DT:
+        refw = torch.nn.Parameter(wc.clone().cuda())
+        for _ in range(2):
+            ops.conv3d(xc.to(dtype), refw, 1, 1).backward(gc.to(dtype))
+        dirw = torch.nn.Parameter(wc.clone().cuda())
+        fp = FlatParams([dirw])
+        for _ in range(2):
+            ops.conv3d(xc.to(dtype), dirw, 1, 1).backward(gc.to(dtype))
+        close(dirw.grad, refw.grad.cpu().double(), torch.float32, f"conv weight {dtype}")
+        assert dirw.grad.data_ptr() == fp.grad.data_ptr() and fp.touched == [True]
+        ops.clear_grad_sinks()
+
 
 def test_fused_adamw_matches_torch(ops):
     from hybrid_ctunet_amd.train import FusedAdamW
