@@ -666,7 +666,8 @@ extern "C" int ctu_permute3(float* src, void* dst, ctu_dtype dd, int64_t n0, int
 
 // out[n] += sum_m x[m][n]; block: 256 threads = (N/8 col groups, capped) x row lanes
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, const int64_t M, const int N, const int ld,
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, const T* __restrict__ row_scale,
+                                                     const int64_t M, const int N, const int ld,
                                                      float* __restrict__ out, const int64_t rows_per_block) {
   __shared__ float red[256 * 8];
   const int ncg = N >> 3;
@@ -684,8 +685,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, co
       for (int64_t m = m_begin + rl; m < m_end; m += rlanes) {
         float v[8];
         load8(x + (size_t)m * ld + cg * 8, v);
+        const float sc = row_scale ? (float)row_scale[m] : 1.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(sc, v[e], acc[e]);
       }
     __syncthreads();
 #pragma unroll
@@ -703,17 +705,58 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, co
     }
   }
 }
-extern "C" int ctu_colsum(ctu_dtype dtype, const void* x, int64_t M, int32_t N, int32_t ld, float* out,
-                          ctu_stream_t stream) {
+extern "C" int ctu_colsum(ctu_dtype dtype, const void* x, const void* row_scale, int64_t M, int32_t N, int32_t ld,
+                          float* out, ctu_stream_t stream) {
   CTU_REQUIRE(x && out && M > 0 && N > 0 && N % 8 == 0 && ld >= N && ld % 8 == 0, "colsum: bad args");
-  int64_t rows = (M + 1023) / 1024;
+  // every workgroup ends with N atomics on the same N addresses: a narrow matrix takes fewer, longer workgroups
+  // (1024 workgroups x 16 columns spent 200 us of a 265 us pass queueing on 16 addresses)
+  const int64_t blocks = N <= 64 ? 256 : 1024;
+  int64_t rows = (M + blocks - 1) / blocks;
   if (rows < 64) rows = 64;
   const unsigned grid = (unsigned)((M + rows - 1) / rows);
   hipStream_t s = (hipStream_t)stream;
   CTU_DISPATCH(dtype,
-               hipLaunchKernelGGL(colsum_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, M, N, ld, out, rows),
-               hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, M, N, ld, out, rows));
+               hipLaunchKernelGGL(colsum_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x,
+                                  (const float*)row_scale, M, N, ld, out, rows),
+               hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x,
+                                  (const bf16*)row_scale, M, N, ld, out, rows));
   return ctu_check_launch("colsum");
+}
+
+// out[m][n] = x[m] * w[n]: the 1x1x1 convolution of a one-channel volume (ResBlock.conv3 shortcut of vit_encoder0,
+// hybrid_CTUNet.py:75-83) - a pure store stream.  grid.x * 256 is a multiple of N / 8: a thread keeps its 8 columns.
+template <typename T>
+__global__ __launch_bounds__(256) void outer_rows_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                         T* __restrict__ out, const int64_t M, const int N) {
+  const int ncg = N >> 3;
+  const int64_t nvec = M * ncg;
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int cg = (int)(i0 % ncg);
+  float wv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) wv[e] = w[cg * 8 + e];
+  for (int64_t i = i0; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const float xv = (float)x[i / ncg];
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = xv * wv[e];
+    store8(out + i * 8, o);
+  }
+}
+extern "C" int ctu_outer_rows(ctu_dtype dtype, const void* x, const float* w, void* out, int64_t M, int32_t N,
+                              ctu_stream_t stream) {
+  CTU_REQUIRE(x && w && out && M > 0 && N > 0 && N % 8 == 0, "outer_rows: bad args");
+  const int ncg = N / 8;
+  int64_t g = (M * ncg + 255) / 256;
+  if (g > 8192) g = 8192;
+  g = ((g + ncg - 1) / ncg) * ncg;
+  hipStream_t s = (hipStream_t)stream;
+  CTU_DISPATCH(dtype,
+               hipLaunchKernelGGL(outer_rows_kernel<float>, dim3((unsigned)g), dim3(256), 0, s, (const float*)x, w,
+                                  (float*)out, M, N),
+               hipLaunchKernelGGL(outer_rows_kernel<bf16>, dim3((unsigned)g), dim3(256), 0, s, (const bf16*)x, w,
+                                  (bf16*)out, M, N));
+  return ctu_check_launch("outer_rows");
 }
 
 // patchify: x [B][H][W][F] (c = 1) -> tokens [B][(h w f)][(p1 p2 pf)]   (vit.py:115)
@@ -906,4 +949,55 @@ extern "C" int ctu_pwa_bwd(ctu_dtype dtype, const void* qkv1, const void* qkv2, 
                hipLaunchKernelGGL(pwa_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)qkv1, (const bf16*)qkv2,
                                   (const bf16*)dout, (bf16*)dqkv1, (bf16*)dqkv2, rows, C, scale));
   return ctu_check_launch("pwa_bwd");
+}
+
+// =========================================================================================================
+// Patch matrix of a one-channel volume: P[m][k] = x[b][od*sd - pd + td][oh*sh - ph + th][ow*sw - pw + tw] for tap
+// k = (td*kh + th)*kw + tw < taps, zero for padding voxels and for taps <= k < kpad (kpad a multiple of 64).
+// The Cin = 1 convolutions (vit_encoder0.conv1 3x3x3, hybrid_CTUNet.py:57-65; ResNet stem 7x7x7 s(2,2,1),
+// resnet.py:150-155) then run as plain LDS-DMA GEMMs: forward out = P W^T (57 MB + the patch matrix instead of a
+// VALU-bound direct convolution at a tenth of the VALU peak), weight gradient dW = dY^T P.  bf16; the image is a few
+// MB and stays in L2, the pass is bound by writing P (16 B per thread).
+// =========================================================================================================
+__global__ __launch_bounds__(256) void im2col_cin1_kernel(const bf16* __restrict__ x, bf16* __restrict__ P, const ctu_geom g,
+                                                          const int taps, const int kpad, const int64_t total) {
+  const int kg = kpad >> 3;  // 8-tap groups per row
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / kg;
+    const int k0 = (int)(i - m * kg) * 8;
+    int t = (int)m;
+    const int ow = t % g.Wo; t /= g.Wo;
+    const int oh = t % g.Ho; t /= g.Ho;
+    const int od = t % g.Do;
+    const int b = t / g.Do;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      float val = 0.f;
+      if (k < taps) {
+        const int tw = k % g.kw;
+        const int tq = k / g.kw;
+        const int th = tq % g.kh, td = tq / g.kh;
+        const int id = od * g.sd - g.pd + td, ih = oh * g.sh - g.ph + th, iw = ow * g.sw - g.pw + tw;
+        if ((unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi)
+          val = (float)x[(((size_t)b * g.Di + id) * g.Hi + ih) * g.Wi + iw];
+      }
+      v[j] = (bf16)val;
+    }
+    *reinterpret_cast<bf16x8*>(P + m * kpad + k0) = v;
+  }
+}
+
+extern "C" int ctu_im2col_cin1(const void* x, void* P, const ctu_geom* g, int32_t kpad, ctu_stream_t stream) {
+  CTU_REQUIRE(x && P && g, "im2col_cin1: null pointer");
+  const int taps = g->kd * g->kh * g->kw;
+  CTU_REQUIRE(kpad >= taps && kpad % 8 == 0, "im2col_cin1: kpad must be a multiple of 8 and >= taps");
+  CTU_REQUIRE(g->B > 0 && g->Do > 0 && g->Ho > 0 && g->Wo > 0 && g->sd > 0 && g->sh > 0 && g->sw > 0, "im2col_cin1: bad geom");
+  const int64_t M = (int64_t)g->B * g->Do * g->Ho * g->Wo;
+  CTU_REQUIRE(M < (1ll << 31), "im2col_cin1: too many rows");
+  const int64_t total = M * (kpad / 8);
+  hipLaunchKernelGGL(im2col_cin1_kernel, dim3(grid_for(total, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)x, (bf16*)P, *g, taps, kpad, total);
+  return ctu_check_launch("im2col_cin1");
 }

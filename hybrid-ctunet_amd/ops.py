@@ -316,7 +316,7 @@ class LinearFn(torch.autograd.Function):
                 gw = gw_buf = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
             _igemm_tn(g, N, x, None, gw_buf, _plain_geom(M, K, N), bias_grad=gb_buf if want_gb else None)
         elif want_gb:
-            call("ctu_colsum", dcode(g.dtype), ptr(g), M, N, N, ptr(gb_buf), stream())
+            call("ctu_colsum", dcode(g.dtype), ptr(g), None, M, N, N, ptr(gb_buf), stream())
         if gw_done is not None:
             gw_done()
         if gb_done is not None:
@@ -577,30 +577,60 @@ class ConvCin1Fn(torch.autograd.Function):
         k = tuple(weight.shape[2:])
         taps = k[0] * k[1] * k[2]
         dout = tuple((n + 2 * p - kk) // s + 1 for n, p, kk, s in zip((D, H, W), padding, k, stride))
-        wf = _packed(weight, "cin1_f", torch.float32, lambda: _pack(weight, (1, taps, N), (0, 1, taps), torch.float32))
         out = torch.empty((B, *dout, N), dtype=x.dtype, device=x.device)
         g = _geom(B, (D, H, W), dout, 8, 0, N, k, stride, padding, 0)
-        call("ctu_conv_cin1_fwd", dcode(x.dtype), ptr(x), ptr(wf), ptr(out), g, stream())
-        ctx.save_for_backward(x, weight)
+        P = None
+        if CIN1_AS_GEMM and x.dtype == torch.bfloat16 and taps > 1 and N % 8 == 0:
+            # patch matrix + LDS-DMA GEMM (the direct VALU kernel reaches a tenth of the VALU peak on the 7x7x7 stem)
+            kpad = (taps + 63) // 64 * 64
+            M = B * dout[0] * dout[1] * dout[2]
+            P = torch.empty((M, kpad), dtype=x.dtype, device=x.device)
+            call("ctu_im2col_cin1", ptr(x), ptr(P), g, kpad, stream())
+
+            def build():
+                w = torch.zeros((N, kpad), dtype=x.dtype, device=x.device)
+                w[:, :taps] = weight.detach().reshape(N, taps)
+                return w
+            _plain_gemm(P, _packed(weight, "cin1_g", x.dtype, build), out, M, kpad, N)
+        elif taps == 1 and tuple(stride) == (1, 1, 1) and N % 8 == 0:
+            # out[m][n] = x[m] * w[n]: a pure store stream
+            call("ctu_outer_rows", dcode(x.dtype), ptr(x), ptr(weight.detach().reshape(N)), ptr(out), x.numel(), N, stream())
+        else:
+            wf = _packed(weight, "cin1_f", torch.float32, lambda: _pack(weight, (1, taps, N), (0, 1, taps), torch.float32))
+            call("ctu_conv_cin1_fwd", dcode(x.dtype), ptr(x), ptr(wf), ptr(out), g, stream())
+        ctx.save_for_backward(x, weight, P)
         ctx.cfg = (stride, padding, k, dout)
         return out
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        x, weight, P = ctx.saved_tensors
         stride, padding, k, dout = ctx.cfg
         gy = gy.contiguous()
         B, D, H, W, _ = x.shape
         N = weight.shape[0]
         taps = k[0] * k[1] * k[2]
         gw = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and P is not None:
+            # dW[n][k] = sum_m dY[m][n] P[m][k] on the saved patch matrix
+            M, kpad = P.shape
+            dwp = torch.zeros((N, kpad), dtype=torch.float32, device=x.device)
+            _igemm_tn(gy, N, P, None, dwp, _plain_geom(M, kpad, N))
+            gw = dwp[:, :taps].reshape(weight.shape)
+        elif ctx.needs_input_grad[1] and taps == 1 and tuple(stride) == (1, 1, 1) and N % 8 == 0:
+            # dW[n] = sum_m x[m] dY[m][n]: column sums of dY weighted by the image
+            gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+            call("ctu_colsum", dcode(gy.dtype), ptr(gy), ptr(x), x.numel(), N, N, ptr(gw), stream())
+        elif ctx.needs_input_grad[1]:
             panel = torch.zeros((taps, N), dtype=torch.float32, device=x.device)
             g = _geom(B, (D, H, W), dout, 8, 0, N, k, stride, padding, 0)
             call("ctu_conv_cin1_wgrad", dcode(x.dtype), ptr(x), ptr(gy), ptr(panel), g, stream())
             gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
             permute3(panel, gw, (1, N, taps), (0, 1, N), (0, taps, 1))
         return None, gw, None, None
+
+
+CIN1_AS_GEMM = True  # tests clear this to run the direct kernels
 
 
 def conv3d_cin1(x, weight, stride, padding):
@@ -740,7 +770,7 @@ class AddBcastFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             per = gy.numel() // ctx.B
             gp = torch.zeros((1, *gy.shape[1:]), dtype=torch.float32, device=gy.device)
-            call("ctu_colsum", dcode(gy.dtype), ptr(gy), ctx.B, per, per, ptr(gp), stream())
+            call("ctu_colsum", dcode(gy.dtype), ptr(gy), None, ctx.B, per, per, ptr(gp), stream())
         return gy, gp
 
 

@@ -110,6 +110,11 @@ int ctu_igemm_nt(ctu_dtype dtype, const void* a1, const void* a2, const void* w,
 int ctu_igemm_tn(ctu_dtype dtype, const void* p, int32_t ldp, const void* q1, const void* q2, float* dw,
                  float* bias_grad, const ctu_geom* g, float* ws, int64_t ws_floats, ctu_stream_t stream);
 
+/* Patch matrix of a one-channel bf16 volume x [B][Di][Hi][Wi]: P[m][k] (bf16, [M][kpad], kpad % 8 == 0, zero for k >= taps and
+ * for padding voxels), m over the Do x Ho x Wo output grid of `g`, k = (td*kh + th)*kw + tw.  With it the Cin == 1
+ * convolutions run as plain GEMMs (ctu_igemm_nt / ctu_igemm_tn on P). */
+int ctu_im2col_cin1(const void* x, void* P, const ctu_geom* g, int32_t kpad, ctu_stream_t stream);
+
 /* Cin == 1 convolutions (vit_encoder0.conv1 1->64 3x3x3, hybrid_CTUNet.py:57-65; ResNet stem 7x7x7 s(2,2,1),
  * resnet.py:150-155).  x: [B][Di][Hi][Wi] ; w: fp32 [taps][N] ; out: [M][N].  kernel 1x1x1 (ResBlock.conv3 shortcut), 3x3x3 or 7x7x7. */
 int ctu_conv_cin1_fwd(ctu_dtype dtype, const void* x, const float* w, void* out, const ctu_geom* g,
@@ -148,9 +153,12 @@ int ctu_pack_frag(const float* src, void* dst, ctu_dtype dst_dtype, int32_t N, i
 int ctu_permute3(float* src, void* dst, ctu_dtype dst_dtype, int64_t n0, int64_t n1, int64_t n2,
                  int64_t s0, int64_t s1, int64_t s2, int64_t d0, int64_t d1, int64_t d2, int32_t accumulate,
                  ctu_stream_t stream);
-/* column sums (bias gradients): out[n] += sum_m x[m][n], x is [M][ld] */
-int ctu_colsum(ctu_dtype dtype, const void* x, int64_t M, int32_t N, int32_t ld, float* out,
+/* column sums (bias gradients): out[n] += sum_m s[m] * x[m][n], x is [M][ld]; s = row_scale [M] (same dtype) or 1 when
+ * NULL.  With s = the one-channel image this is the weight gradient of a 1x1x1 Cin = 1 convolution. */
+int ctu_colsum(ctu_dtype dtype, const void* x, const void* row_scale, int64_t M, int32_t N, int32_t ld, float* out,
                ctu_stream_t stream);
+/* out[m][n] = x[m] * w[n] (w fp32): forward of a 1x1x1 convolution of a one-channel volume. */
+int ctu_outer_rows(ctu_dtype dtype, const void* x, const float* w, void* out, int64_t M, int32_t N, ctu_stream_t stream);
 
 /* K6/K7 InstanceNorm3d (eps 1e-5, no affine) fused with residual add and LeakyReLU(0.01)
  * (resnet.py:97-124,156-157,198; hybrid_CTUNet.py:84-104).  x: [B][S][C]; acc_ws: fp64 [B][C][2] workspace, zero on

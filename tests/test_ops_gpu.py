@@ -227,7 +227,20 @@ def test_conv_transpose(ops, dtype, k):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("k,s,p,dims", [((3, 3, 3), (1, 1, 1), (1, 1, 1), (9, 10, 12)), ((7, 7, 7), (2, 2, 1), (3, 3, 3), (12, 14, 10)),
                                         ((1, 1, 1), (1, 1, 1), (0, 0, 0), (5, 6, 7))])
-def test_conv_cin1(ops, dtype, k, s, p, dims):
+@pytest.mark.parametrize("as_gemm", [True, False])
+def test_conv_cin1(ops, dtype, k, s, p, dims, as_gemm):
+    """as_gemm: bf16 multi-tap Cin=1 convs run as patch matrix (ctu_im2col_cin1) + LDS-DMA GEMMs; False pins the direct
+    VALU kernels (the only path in fp32 / for 1x1x1)."""
+    if as_gemm and (dtype == torch.float32 or k == (1, 1, 1)):
+        pytest.skip("direct kernel in this configuration")
+    ops.CIN1_AS_GEMM = as_gemm
+    try:
+        _conv_cin1_case(ops, dtype, k, s, p, dims)
+    finally:
+        ops.CIN1_AS_GEMM = True
+
+
+def _conv_cin1_case(ops, dtype, k, s, p, dims):
     B, N = 2, 64
     x, xh = dev(rnd((B, *dims, 1), 1), dtype)
     w, wh = dev(rnd((N, 1, *k), 2, 1 / math.sqrt(k[0] * k[1] * k[2])), torch.float32, True)
