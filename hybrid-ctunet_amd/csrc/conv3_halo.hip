@@ -30,6 +30,7 @@ struct HaloArgs {
   int B, D, H, W, C1, C2, N, n_split, ldc, ldc2;
   int nbd, nbh, nbw, ntn;  // brick grid, 32-wide n tiles in the whole panel
   double* in_acc;          // optional [B][N][2]: += (sum y, sum y^2) per batch item and channel (InstanceNorm statistics)
+  const void* residual;    // optional [rows][ldc] (same dtype): added to the result (bf16 DMA kernel, n_split == 0)
   float* part;             // split over input channels (small volumes): fp32 partial outputs [split][rows][ntn * 32], else NULL
   int hc_per_split;        // 16-channel half chunks per split (blockIdx.z)
 };
@@ -390,7 +391,15 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_dma_kernel(const HaloArgs p
           const size_t m = (((size_t)b * p.D + gd) * p.H + gh) * p.W + gw;
           if (p.part) store8(p.part + ((size_t)blockIdx.z * p.B * p.D * p.H * p.W + m) * (p.ntn * 32) + n, xv);
           else if (p.n_split > 0 && n >= p.n_split) store8(out2 + m * p.ldc2 + (n - p.n_split), xv);
-          else store8(out + m * p.ldc + n, xv);
+          else {
+            if (p.residual) {
+              float rr[8];
+              load8(reinterpret_cast<const bf16*>(p.residual) + m * p.ldc + n, rr);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) xv[e] += rr[e];
+            }
+            store8(out + m * p.ldc + n, xv);
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -461,7 +470,7 @@ template <> struct HaloDma<bf16> {
     const int blocks = bricks * (ntn / NT);
     int ksplit = 1;
     const int64_t rows = (int64_t)p.B * p.D * p.H * p.W;
-    if (ws && blocks < 256 && rows <= 16384 && HCT >= 4 && p.n_split == 0 && p.N % 8 == 0 && p.N <= 2048 && p.ldc % 8 == 0) {
+    if (ws && !p.residual && blocks < 256 && rows <= 16384 && HCT >= 4 && p.n_split == 0 && p.N % 8 == 0 && p.N <= 2048 && p.ldc % 8 == 0) {
       ksplit = (512 + blocks - 1) / blocks;
       if (ksplit > HCT / 2) ksplit = HCT / 2;  // at least two half chunks (18 stages) per workgroup
       const int64_t cap = ws_floats / (rows * ntn * 32);
@@ -505,8 +514,8 @@ static int launch_halo(const HaloArgs& p, float* ws, int64_t ws_floats, hipStrea
 
 extern "C" int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, const void* wfrag, void* out, void* out2,
                               int32_t B, int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N,
-                              int32_t n_split, int32_t ldc, int32_t ldc2, double* in_acc, float* ws, int64_t ws_floats,
-                              ctu_stream_t stream) {
+                              int32_t n_split, int32_t ldc, int32_t ldc2, double* in_acc, const void* residual, float* ws,
+                              int64_t ws_floats, ctu_stream_t stream) {
   CTU_REQUIRE(x1 && wfrag && out, "conv3_halo: null pointer");
   CTU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3_halo: bad dims");
   CTU_REQUIRE(C1 > 0 && C1 % 32 == 0 && C2 >= 0 && C2 % 32 == 0 && (C2 == 0 || x2), "conv3_halo: C1, C2 must be multiples of 32");
@@ -516,6 +525,10 @@ extern "C" int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, c
   p.x1 = x1; p.x2 = x2; p.wfrag = wfrag; p.out = out; p.out2 = out2;
   p.B = B; p.D = D; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.N = N; p.n_split = n_split; p.ldc = ldc; p.ldc2 = ldc2;
   p.in_acc = in_acc;
+  p.residual = residual;
+  CTU_REQUIRE(!residual || (dtype == CTU_BF16 && n_split == 0 && !in_acc &&
+                            (int64_t)B * D * H * W * (C1 > C2 ? C1 : C2) < (1ll << 31)),
+              "conv3_halo: a residual input needs the bf16 LDS-DMA kernel without split / statistics");
   p.part = nullptr;
   p.hc_per_split = (C1 + C2) / 16;
   CTU_REQUIRE(ws_floats >= 0 && (ws_floats == 0 || ws), "conv3_halo: bad workspace");

@@ -50,13 +50,16 @@ class ResBlock(nn.Module):
             self.downsample = True
 
     def forward(self, inp, inp2=None):
-        out = ops.instance_norm(self.conv1(inp, inp2), None, True)
+        # identity shortcut: its gradient is folded into conv1's data-gradient epilogue (ops.GradStash) instead of an
+        # autograd accumulation pass over three full-size tensors
+        stash = [] if (not self.downsample and inp.requires_grad and torch.is_grad_enabled()) else None
+        out = ops.instance_norm(self.conv1(inp, inp2, grad_stash=stash), None, True)
         out = self.conv2(out)
         if self.downsample:
             residual = ops.instance_norm(self.conv3(inp, inp2), None, False)
         else:
             assert inp2 is None
-            residual = inp
+            residual = ops.GradStash.apply(inp, stash) if stash is not None else inp
         return ops.instance_norm(out, residual, True)  # norm2 -> += residual -> LeakyReLU (:99-104)
 
 

@@ -82,8 +82,7 @@ class ConvLayer(nn.Module):
         if x2 is None and self.kernel_size == (1, 1, 1) and self.stride == (1, 1, 1):
             # every 1x1x1 ConvLayer of these networks feeds an InstanceNorm
             return ops.linear(x, w, in_stats=True, grad_stash=grad_stash)
-        assert grad_stash is None
-        return ops.conv3d(x, w, self.stride, self.padding, x2)
+        return ops.conv3d(x, w, self.stride, self.padding, x2, grad_stash=grad_stash)
 
 
 def get_conv_layer(spatial_dims: int, in_channels: int, out_channels: int, kernel_size=3, stride=1, act=None,

@@ -359,8 +359,9 @@ class ConvFn(torch.autograd.Function):
     Reference: get_conv_layer, networks/resnet.py:17-50 (3x3x3 s1/s2, 1x1x1 s2)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, stride, padding):
+    def forward(ctx, x1, x2, weight, stride, padding, grad_stash=None):
         _check_act(x1)
+        ctx.grad_stash = grad_stash
         B, D, H, W, C1 = x1.shape
         C2 = 0 if x2 is None else x2.shape[-1]
         N = weight.shape[0]
@@ -378,7 +379,7 @@ class ConvFn(torch.autograd.Function):
                 acc = _in_acc_take(x1.device, B * N * 2)
             ws = _tn_workspace(x1.device)
             call("ctu_conv3_halo", dcode(x1.dtype), ptr(x1), ptr(x2), ptr(wfr), ptr(out), None, B, D, H, W, C1, C2, N, 0,
-                 N, 0, ptr(acc[1]) if acc is not None else None, ptr(ws), ws.numel(), stream())
+                 N, 0, ptr(acc[1]) if acc is not None else None, None, ptr(ws), ws.numel(), stream())
             ctx.in_acc = acc
         else:
             wf = _packed(weight, "conv_f", x1.dtype,
@@ -411,8 +412,13 @@ class ConvFn(torch.autograd.Function):
                 wfr = _packed(weight, "conv_hd", x1.dtype,
                               lambda: _pack_frag(weight, K, N, taps, taps, K * taps, 1, 1, x1.dtype))
                 ws = _tn_workspace(x1.device)
+                extra = None
+                if ctx.grad_stash and x2 is None and x1.dtype == torch.bfloat16 and B * D * H * W * max(N, K) < (1 << 31):
+                    extra = ctx.grad_stash.pop()  # gradient of x1 through another branch: added in the epilogue
+                    if extra.shape != x1.shape or extra.dtype != x1.dtype or not extra.is_contiguous():
+                        extra = extra.to(x1.dtype).contiguous().view_as(x1)
                 call("ctu_conv3_halo", dcode(x1.dtype), ptr(gy), None, ptr(wfr), ptr(g1), ptr(g2), B, D, H, W, N, 0, K,
-                     C1 if x2 is not None else 0, C1, C2, None, ptr(ws), ws.numel(), stream())
+                     C1 if x2 is not None else 0, C1, C2, None, ptr(extra), ptr(ws), ws.numel(), stream())
             else:
                 # dX[v][c] = sum_t sum_n dY[(v + p - t)/s][n] W[n][c][t]  ->  panel [t][c][n]
                 wd = _packed(weight, "conv_d", x1.dtype,
@@ -441,7 +447,9 @@ class ConvFn(torch.autograd.Function):
             else:
                 gw = torch.empty(weight.shape, dtype=torch.float32, device=x1.device)
                 permute3(panel, gw, (N, K, taps), (K, 1, N * K), (K * taps, taps, 1))
-        return g1, g2, gw, None, None
+        if ctx.grad_stash:  # not consumed by a fused epilogue (generic path): add it here
+            g1 = g1 + ctx.grad_stash.pop().to(g1.dtype)
+        return g1, g2, gw, None, None, None
 
 
 _PANEL_SCRATCH = {}
@@ -483,10 +491,10 @@ def _pack(weight, n, src_strides, dtype):
     return out
 
 
-def conv3d(x1, weight, stride=1, padding=0, x2=None):
+def conv3d(x1, weight, stride=1, padding=0, x2=None, grad_stash=None):
     global _last_in_acc
     _last_in_acc = None
-    out = ConvFn.apply(x1, x2, weight, _t3(stride), _t3(padding))
+    out = ConvFn.apply(x1, x2, weight, _t3(stride), _t3(padding), grad_stash)
     if _last_in_acc is not None:
         out._ctu_in_acc = _last_in_acc  # instance_norm(out, ...) picks the statistics up instead of re-reading `out`
         _last_in_acc = None
