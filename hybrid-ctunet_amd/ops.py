@@ -151,6 +151,16 @@ def _splitk_for(M: int, N: int, K: int, dma: bool = False) -> int:
     return max(1, min(16, K // 128, 512 // tiles))
 
 
+def _conv_splitk(M: int, N: int, K: int, taps: int) -> int:
+    """Split of the (tap, 32-channel chunk) loop of a gathered conv on the generic implicit-GEMM kernel: the strided
+    3x3x3 convs at 6x6x12 / 12x12x24 have 14-108 output tiles and a reduction of 27 x 256."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128 if N > 64 else 1)
+    its = taps * ((K + 31) // 32)
+    if tiles >= 128 or its < 32:
+        return 1
+    return max(1, min(its // 8, (255 + tiles) // tiles))
+
+
 _SPLITK_WS = {}
 
 
@@ -385,7 +395,9 @@ class ConvFn(torch.autograd.Function):
             wf = _packed(weight, "conv_f", x1.dtype,
                          lambda: _pack(weight, (taps, N, K), (1, K * taps, taps), x1.dtype))
             g = _geom(B, (D, H, W), dout, C1, C2, N, k, stride, padding, 0)
-            _igemm_nt(x1, x2, wf, out, g, _epi(N))
+            M = B * dout[0] * dout[1] * dout[2]
+            sk = _conv_splitk(M, N, K, taps)
+            _igemm_nt(x1, x2, wf, out, g, _epi(N, splitk=sk, splitk_ws=_splitk_workspace(x1.device, M * N) if sk > 1 else None))
         ctx.save_for_backward(x1, x2, weight)
         ctx.cfg = (stride, padding, k, dout)
         if getattr(ctx, "in_acc", None) is not None:
@@ -424,7 +436,10 @@ class ConvFn(torch.autograd.Function):
                 wd = _packed(weight, "conv_d", x1.dtype,
                              lambda: _pack(weight, (taps, K, N), (1, taps, K * taps), x1.dtype))
                 gd = _geom(B, dout, (D, H, W), N, 0, K, k, stride, padding, 1)
-                _igemm_nt(gy, None, wd, g1, gd, _epi(C1, out2=g2, n_split=C1 if x2 is not None else 0, ldc2=C2))
+                Mi = B * D * H * W
+                sk = _conv_splitk(Mi, K, N, taps) if x2 is None else 1
+                _igemm_nt(gy, None, wd, g1, gd, _epi(C1, out2=g2, n_split=C1 if x2 is not None else 0, ldc2=C2, splitk=sk,
+                                                     splitk_ws=_splitk_workspace(x1.device, Mi * K) if sk > 1 else None))
         if ctx.needs_input_grad[2]:
             gw_buf, gw_done = _direct_grad(weight) if taps > 1 else (None, None)
             if gw_buf is not None:
