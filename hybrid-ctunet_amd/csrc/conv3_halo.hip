@@ -183,15 +183,17 @@ __device__ __forceinline__ void halo_row_to_hw(int row, int& hh, int& ww) {
   ww = 4 * ((q >> 1) & 1) + (row & 3);
 }
 
-template <int NT>
-__global__ __launch_bounds__(256, 2) void conv3_halo_dma_kernel(const HaloArgs p) {
+// RD = depth of the weight ring: RD - 1 stages are in flight ahead of the one computed.  NT <= 2 takes RD = 2: with
+// 51 KiB of LDS and ~110 VGPRs three workgroups fit a CU, and their interleaving hides more than a deeper ring does.
+template <int NT, int RD = (NT <= 2 ? 2 : 3)>
+__global__ __launch_bounds__(256, RD == 2 ? 3 : 2) void conv3_halo_dma_kernel(const HaloArgs p) {
   constexpr int HINS = 19;            // DMA wave-instructions per halo half chunk (1216 slots >= 600 voxels x 2)
   constexpr int HBUF = HINS * 1024;
   constexpr int SFR = 3 * NT;         // weight fragments (1 KiB each) per stage of 3 taps
   constexpr int SBYTES = SFR * 1024;
   constexpr int RING0 = 2 * HBUF;
   constexpr int STAGE_LD = 32 + 4;
-  constexpr int LDS_MAIN = RING0 + 3 * SBYTES;
+  constexpr int LDS_MAIN = RING0 + RD * SBYTES;
   constexpr int LDS_EPI = 4 * 32 * STAGE_LD * 4;
   constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
@@ -277,19 +279,19 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_dma_kernel(const HaloArgs p
 
   issue_halo(hc_b);
   issue_b(hc_b, 0, 0);
-  issue_b(hc_b, 1, 1);
-  int hc = hc_b, s = 0, rs = 0;     // stage being computed: half chunk, (td, th) index, ring slot
-  int ihc = hc_b, is = 2, irs = 2;  // stage being fetched (two ahead)
+  if (RD == 3) issue_b(hc_b, 1, 1);
+  int hc = hc_b, s = 0, rs = 0;               // stage being computed: half chunk, (td, th) index, ring slot
+  int ihc = hc_b, is = RD - 1, irs = RD - 1;  // stage being fetched (RD - 1 ahead)
   for (int u = 0; u < U; ++u) {
-    // own DMAs of this stage (and, being older, of its halo) have landed; still in flight: the next stage and a
-    // halo prefetch issued in one of the last two stages
-    const bool halo_in_flight = (s == 1 || s == 2) && hc + 1 < HC;
-    wait_vm_then_barrier_n(b_w + (halo_in_flight ? h_w : 0));
+    // own DMAs of this stage (and, being older, of its halo) have landed; still in flight: the RD - 2 younger weight
+    // stages and a halo prefetch issued in one of the last RD - 1 stages (it is issued after that stage's weights)
+    const bool halo_in_flight = (s == 1 || (RD == 3 && s == 2)) && hc + 1 < HC;
+    wait_vm_then_barrier_n((RD - 2) * b_w + (halo_in_flight ? h_w : 0));
     issue_b(ihc, is, irs);  // past the end: refetches the last stage into a slot nobody reads (keeps the counts)
-    if (u + 3 < U) {
+    if (u + RD < U) {
       if (++is == 9) { is = 0; ++ihc; }
     }
-    irs = irs == 2 ? 0 : irs + 1;
+    irs = irs == RD - 1 ? 0 : irs + 1;
     if (s == 0 && hc + 1 < HC) issue_halo(hc + 1);
 
     const int td = (s * 11) >> 5, th = s - 3 * td;
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_dma_kernel(const HaloArgs p
         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     if (++s == 9) { s = 0; ++hc; }
-    rs = rs == 2 ? 0 : rs + 1;
+    rs = rs == RD - 1 ? 0 : rs + 1;
   }
   wait_vm_then_barrier<0>();  // the tail refetches have landed; LDS is free for the epilogue
 
