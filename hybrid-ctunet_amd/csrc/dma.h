@@ -34,7 +34,10 @@ __device__ __forceinline__ void wait_vm_then_barrier_n(int n) {  // n is wave-un
     case 6: wait_vm_then_barrier<6>(); break;
     case 7: wait_vm_then_barrier<7>(); break;
     case 8: wait_vm_then_barrier<8>(); break;
-    default: wait_vm_then_barrier<0>(); break;
+    case 12: wait_vm_then_barrier<12>(); break;
+    case 16: wait_vm_then_barrier<16>(); break;
+    case 24: wait_vm_then_barrier<24>(); break;
+    default: wait_vm_then_barrier<0>(); break;  // (any other count: wait for everything - always safe)
   }
 }
 

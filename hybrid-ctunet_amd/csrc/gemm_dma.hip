@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256, (R * (TN + TC) * 128 > 80 * 1024) ? 1 : 2) voi
   constexpr int STAGE = (NP + NQ) * PANEL;
   constexpr int PI = NP, QI = NQ;              // DMA instructions per wave and stage (4 per panel, 4 waves)
   constexpr int AI = TN / 64, AJ = TC / 64;    // MFMA tiles per wave
-  static_assert((R - 2) * (PI + QI) <= 8, "counted vmcnt switch covers 0..8");
+  static_assert((R - 2) * (PI + QI) <= 8 || (R - 2) * (PI + QI) == 16, "counted vmcnt switch: 0..8, 12, 16, 24");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[R * STAGE];
 
   const int tid = threadIdx.x;
@@ -471,7 +471,6 @@ __global__ __launch_bounds__(256, (R * (TN + TC) * 128 > 80 * 1024) ? 1 : 2) voi
     }
   }
 
-  const bool single = a.splits == 1;
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
 #pragma unroll
@@ -483,8 +482,9 @@ __global__ __launch_bounds__(256, (R * (TN + TC) * 128 > 80 * 1024) ? 1 : 2) voi
         const int c = c0 + (wc * AJ + j) * 32 + r;
         if (c < a.C) {
           const size_t o = (size_t)n * a.C + c;
+          // (a plain `dw[o] += v` for a sole writer is a dependent load-add-store per element: 64 serialized global
+          // round trips per lane, 25 us of a 35 us trunk launch; the no-return atomic is fire-and-forget)
           if (a.part) a.part[(size_t)split * a.N * a.C + o] = acc[i][j][e];
-          else if (single) a.dw[o] += acc[i][j][e];
           else atomicAdd(&a.dw[o], acc[i][j][e]);
         }
       }
