@@ -25,18 +25,9 @@ struct WorkItem {
   int m0, n0, kb, ke;  // tile origin, k-step range [kb, ke)
 };
 
-// y = act(x + bias) + residual -> out / out2 / scattered out, 8 consecutive n of row m (the ctu_epilogue contract)
-__device__ __forceinline__ void epilogue_store8(const ctu_epilogue& ep, bf16* out, int m, int n, float (&x)[8]) {
-  if (ep.bias) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] += ep.bias[n + e];
-  }
-  if (ep.act == 1) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = gelu_erf(x[e]);
-  }
-  bf16* dst = out;
-  size_t off;
+// destination of the 8 consecutive columns n.. of row m under the ctu_epilogue contract (plain / split / scattered)
+__device__ __forceinline__ size_t epilogue_offset(const ctu_epilogue& ep, bf16* out, int m, int n, bf16*& dst) {
+  dst = out;
   if (ep.scatter) {
     const int tap = n / ep.n_per_tap, co = n - tap * ep.n_per_tap;
     const int tw = tap % ep.sc_kw;
@@ -49,20 +40,13 @@ __device__ __forceinline__ void epilogue_store8(const ctu_epilogue& ep, bf16* ou
     const int bb = t / ep.sc_D;
     const size_t orow = (((size_t)bb * (ep.sc_D * ep.sc_kd) + dd * ep.sc_kd + td) * (ep.sc_H * ep.sc_kh) + hh * ep.sc_kh + th) *
                             (size_t)(ep.sc_W * ep.sc_kw) + ww * ep.sc_kw + tw;
-    off = orow * ep.ldc + co;
-  } else if (ep.n_split > 0 && n >= ep.n_split) {
+    return orow * ep.ldc + co;
+  }
+  if (ep.n_split > 0 && n >= ep.n_split) {
     dst = reinterpret_cast<bf16*>(ep.out2);
-    off = (size_t)m * ep.ldc2 + (n - ep.n_split);
-  } else {
-    off = (size_t)m * ep.ldc + n;
+    return (size_t)m * ep.ldc2 + (n - ep.n_split);
   }
-  if (ep.residual) {
-    float rr[8];
-    load8(reinterpret_cast<const bf16*>(ep.residual) + off, rr);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] += rr[e];
-  }
-  store8(dst + off, x);
+  return (size_t)m * ep.ldc + n;
 }
 
 }  // namespace
@@ -269,7 +253,31 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) voi
 #pragma unroll
             for (int e = 0; e < 16; ++e) { const float v = acc[i][j][e]; rs1[j] += v; rs2[j] += v * v; }
       }
-      // epilogue through a wave-private 16 x 32 fp32 patch (outside the DMA ring: the next tile is already in flight)
+      // epilogue through a wave-private 16 x 32 fp32 patch (outside the DMA ring: the next tile is already in flight).
+      // The residual vectors of all 2 MI NJ patches are requested FIRST: loaded patch by patch they are 2 MI NJ
+      // dependent global round trips per tile (most of a short trunk GEMM's life).
+      const int erow = lane >> 2, ecv = lane & 3;
+      const bool want_res = p.ep.residual != nullptr && p.splitk <= 1;
+      bf16x8 resv[MI * NJ * 2];
+      if (want_res) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              const int m = cur.m0 + wm * WM + i * 32 + half * 16 + erow, n = cur.n0 + wn * WN + j * 32 + ecv * 8;
+              bf16x8 v;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+              if (m < p.M && n < p.N) {
+                bf16* dst;
+                const size_t off = epilogue_offset(p.ep, out, m, n, dst);
+                v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.ep.residual) + off);
+              }
+              resv[(i * NJ + j) * 2 + half] = v;
+            }
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -291,12 +299,26 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) voi
                   atomicAdd(p.ws + (size_t)(mb + row) * p.N + nb + col, stage[row * EPI_LD + col]);
               }
             } else {
-              const int row = lane >> 2, cv = lane & 3;
-              const int m = mb + row, n = nb + cv * 8;
+              const int m = mb + erow, n = nb + ecv * 8;
               if (m < p.M && n < p.N) {
                 float x[8];
-                load8(&stage[row * EPI_LD + cv * 8], x);
-                epilogue_store8(p.ep, out, m, n, x);
+                load8(&stage[erow * EPI_LD + ecv * 8], x);
+                if (p.ep.bias) {
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) x[e] += p.ep.bias[n + e];
+                }
+                if (p.ep.act == 1) {
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) x[e] = gelu_erf(x[e]);
+                }
+                if (want_res) {
+                  const bf16x8 rv = resv[(i * NJ + j) * 2 + half];
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) x[e] += (float)rv[e];
+                }
+                bf16* dst;
+                const size_t off = epilogue_offset(p.ep, out, m, n, dst);
+                store8(dst + off, x);
               }
             }
             __builtin_amdgcn_wave_barrier();
