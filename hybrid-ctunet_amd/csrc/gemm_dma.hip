@@ -58,15 +58,19 @@ __device__ __forceinline__ size_t epilogue_offset(const ctu_epilogue& ep, bf16* 
 // BT = true ("NN"): W is stored reduction-major, W[k][n] with leading dimension N - the data gradient of a Linear /
 // 1x1x1 conv reads the forward weight [N_fwd][K_fwd] as is, no transposed copy.  Its B tile is staged as 32-column
 // panels [panel][64 k rows][32 n] (64-B rows, plain DMA) and read transposed, exactly like the TN kernel's operands.
-template <int BM, int BN, int R, bool BT>
-__global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) void gemm_nt_dma_kernel(const GemmNtArgs p) {
-  constexpr int BK = 64;
+// BK = 32 serves K % 64 == 32 (the 32-channel layers): 64-B LDS rows, four to a bank row, slot ^ ((row >> 2) & 3).
+template <int BM, int BN, int R, bool BT, int BK = 64>
+__global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) void gemm_nt_dma_kernel(const GemmNtArgs p) {
+  static_assert(BK == 64 || (BK == 32 && !BT), "stage depth");
+  constexpr int ROWB = BK * 2;         // bytes of a tile row in LDS
+  constexpr int SPR = BK / 8;          // 16-B slots per row
+  constexpr int RPI = 1024 / ROWB;     // tile rows per DMA wave-instruction
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int WM = BM / 2, WN = BN / 2;  // wave tile: WM rows x WN columns (waves 2 x 2)
   constexpr int MI = WM / 32, NJ = WN / 32;
-  constexpr int APW = BM / 32;     // DMA instructions (8 rows of 128 B each) per wave and stage: A ...
-  constexpr int BPW = BN / 32;     // ... and B
+  constexpr int APW = BM / RPI / 4;  // DMA instructions (1 KiB = RPI rows each) per wave and stage: A ...
+  constexpr int BPW = BN / RPI / 4;  // ... and B
   constexpr int EPI_LD = 32 + 4;
   constexpr int EPI_BYTES = 4 * 16 * EPI_LD * 4;
   constexpr int IPW = APW + BPW;   // DMA instructions per wave and stage
@@ -79,6 +83,8 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) voi
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int vid = xcd_remap(blockIdx.x, gridDim.x);
+  // source-side bank swizzle of a tile row's 16-B slots (conflict-free ds_read_b128 of 32-row fragments)
+  auto swz = [](int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; };
 
   auto decode = [&](int wi) {
     WorkItem it;
@@ -97,8 +103,8 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) voi
   int arow[APW], aslot[APW], brow[BPW], bslot[BPW];
 #pragma unroll
   for (int j = 0; j < APW; ++j) {
-    arow[j] = 8 * APW * wave + 8 * j + (lane >> 3);
-    aslot[j] = (lane & 7) ^ ((arow[j] >> 1) & 7);
+    arow[j] = RPI * (APW * wave + j) + lane / SPR;
+    aslot[j] = (lane % SPR) ^ swz(arow[j]);
   }
 #pragma unroll
   for (int j = 0; j < BPW; ++j) {
@@ -107,8 +113,8 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) voi
       brow[j] = (ins & 3) * 16 + (lane >> 2);
       bslot[j] = (ins >> 2) * 32 + (lane & 3) * 8;
     } else {
-      brow[j] = 8 * BPW * wave + 8 * j + (lane >> 3);
-      bslot[j] = (lane & 7) ^ ((brow[j] >> 1) & 7);
+      brow[j] = RPI * (BPW * wave + j) + lane / SPR;
+      bslot[j] = (lane % SPR) ^ swz(brow[j]);
     }
   }
 
@@ -136,18 +142,18 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) voi
     }
   };
 
-  // fragment read offsets inside a stage: row * 128 + ((slot ^ ((row >> 1) & 7)) << 4), slot = 2 kk + h
+  // fragment read offsets inside a stage: row * ROWB + ((slot ^ swz(row)) << 4), slot = 2 kk + h
   int aoff[MI], boff[NJ];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int row = wm * WM + i * 32 + r;
-    aoff[i] = row * 128 + ((h ^ ((row >> 1) & 7)) << 4);
+    aoff[i] = row * ROWB + ((h ^ swz(row)) << 4);
   }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int row = wn * WN + j * 32 + r;
     if constexpr (BT) boff[j] = A_BYTES + (wn * NJ + j) * 4096 + (h * 8 * 32 + r) * 2;  // panel, k row 8 h, column r
-    else boff[j] = A_BYTES + row * 128 + ((h ^ ((row >> 1) & 7)) << 4);
+    else boff[j] = A_BYTES + row * ROWB + ((h ^ swz(row)) << 4);
   }
 
   f32x16 acc[MI][NJ];
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * 128 > 76 * 1024) ? 1 : 2) voi
 
     const unsigned char* sa = smem + st * STAGE;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < BK / 16; ++kk) {
       bf16x8 fa[MI], fb[NJ];
 #pragma unroll
       for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + (aoff[i] ^ (kk << 5)));
@@ -345,14 +351,15 @@ int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {
   // tile choice: the largest tile that still yields ~200 work items for the 512 resident workgroups; the 864-token
   // ViT trunk (M = 864) gets 64 x 64 tiles rather than a split K with its atomics and second pass
   const auto items = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  const bool bk32 = p.K % 64 != 0;  // (K % 32 == 0 checked by the caller); 128-row tiles only
   int BM = 128, BN = p.N <= 64 ? 64 : 128;
-  if (items(BM, BN) < 200 && p.splitk <= 1) {
+  if (!bk32 && items(BM, BN) < 200 && p.splitk <= 1) {
     BN = 64;
     if (items(BM, BN) < 200) BM = 64;
   }
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  p.ksteps = p.K / 64;
+  p.ksteps = p.K / (bk32 ? 32 : 64);
   if (p.splitk > p.ksteps) p.splitk = p.ksteps;
   if (p.splitk < 1) p.splitk = 1;
   p.ks_per_split = (p.ksteps + p.splitk - 1) / p.splitk;
@@ -363,7 +370,11 @@ int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {
   const bool one_per_cu = p.nwork <= 256;  // a single workgroup per CU may take the whole LDS for a deeper ring
   const int grid = p.nwork < 512 ? p.nwork : 512;  // else two resident workgroups per CU, persistent over the work items
   const dim3 g(grid), b(256);
-  if (p.w_kn) {
+  if (bk32) {
+    if (p.w_kn) return -1;
+    if (BN == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 64, 3, false, 32>), g, b, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128, 3, false, 32>), g, b, 0, stream, p);
+  } else if (p.w_kn) {
     if (BM == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 64, 4, true>), g, b, 0, stream, p);
     else if (BN == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 64, 2, true>), g, b, 0, stream, p);
     else if (one_per_cu) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128, 3, true>), g, b, 0, stream, p);

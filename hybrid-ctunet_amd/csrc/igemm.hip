@@ -279,7 +279,10 @@ template <> struct NtDma<bf16> {
   static bool launch(const void* a1, const void* a2, const void* w, void* out, const ctu_geom* g, const ctu_epilogue* ep,
                      NtArgs& p, hipStream_t stream) {
     const int K = g->C1 + g->C2;
-    if (!geom_is_plain(g) || K % 64 != 0 || (g->C2 > 0 && g->C1 % 64 != 0) || ctu_option_generic_gemm()) return false;
+    // 64-deep stages; K % 64 == 32 runs the 32-deep variant (single source, row-major W only)
+    const bool k32 = K % 64 == 32 && g->C2 == 0 && !ep->w_kn;
+    if (!geom_is_plain(g) || (K % 64 != 0 && !k32) || (g->C2 > 0 && g->C1 % 64 != 0) || ctu_option_generic_gemm())
+      return false;
     GemmNtArgs q;
     q.a1 = reinterpret_cast<const bf16*>(a1); q.a2 = reinterpret_cast<const bf16*>(a2);
     q.w = reinterpret_cast<const bf16*>(w); q.out = out; q.ep = *ep;

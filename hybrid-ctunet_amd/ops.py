@@ -228,7 +228,7 @@ def _igemm_tn(p, ldp, q1, q2, dw, g: Geom, bias_grad=None):
 
 def _plain_gemm(x, w, out, M, K, N, bias=None, residual=None, act=0, w_kn=0, in_acc=None, in_rows=0):
     """out[M,N] = act(x[M,K] @ w[N,K]^T + bias) + residual, with split-K when there are few tiles and a long K."""
-    sk = 1 if in_acc is not None else _splitk_for(M, N, K, dma=x.dtype == torch.bfloat16 and K % 64 == 0)
+    sk = 1 if in_acc is not None else _splitk_for(M, N, K, dma=x.dtype == torch.bfloat16 and K % 32 == 0)
     ws = _splitk_workspace(x.device, M * N) if sk > 1 else None
     _igemm_nt(x, None, w, out, _plain_geom(M, K, N),
               _epi(N, bias=bias, residual=residual, act=act, splitk_ws=ws, splitk=sk, w_kn=w_kn, in_acc=in_acc,
@@ -262,7 +262,7 @@ class LinearFn(torch.autograd.Function):
         N, K = weight.shape[0], weight[0].numel()
         M = x.numel() // K
         acc, rows = None, 0
-        if (in_stats and FUSE_IN_STATS and USE_W_KN and x.dtype == torch.bfloat16 and K % 64 == 0 and x.dim() >= 3
+        if (in_stats and FUSE_IN_STATS and USE_W_KN and x.dtype == torch.bfloat16 and K % 32 == 0 and x.dim() >= 3
                 and bias is None and residual is None and act == 0):
             rows = M // x.shape[0]  # rows per batch item: a 1x1x1 conv whose output feeds an InstanceNorm
             if rows % 128 == 0 and rows * x.shape[0] == M:
@@ -614,7 +614,13 @@ class ConvCin1Fn(torch.autograd.Function):
                 w = torch.zeros((N, kpad), dtype=x.dtype, device=x.device)
                 w[:, :taps] = weight.detach().reshape(N, taps)
                 return w
-            _plain_gemm(P, _packed(weight, "cin1_g", x.dtype, build), out, M, kpad, N)
+            rows = M // B
+            acc = _in_acc_take(x.device, B * N * 2) if (FUSE_IN_STATS and rows % 128 == 0) else None
+            _plain_gemm(P, _packed(weight, "cin1_g", x.dtype, build), out, M, kpad, N,
+                        in_acc=acc[1] if acc is not None else None, in_rows=rows)
+            if acc is not None:  # these convs feed an InstanceNorm: its sums come from the GEMM epilogue
+                global _last_in_acc
+                _last_in_acc = acc
         elif taps == 1 and tuple(stride) == (1, 1, 1) and N % 8 == 0:
             # out[m][n] = x[m] * w[n]: a pure store stream
             call("ctu_outer_rows", dcode(x.dtype), ptr(x), ptr(weight.detach().reshape(N)), ptr(out), x.numel(), N, stream())
@@ -657,7 +663,13 @@ CIN1_AS_GEMM = True  # tests clear this to run the direct kernels
 
 
 def conv3d_cin1(x, weight, stride, padding):
-    return ConvCin1Fn.apply(x, weight, _t3(stride), _t3(padding))
+    global _last_in_acc
+    _last_in_acc = None
+    out = ConvCin1Fn.apply(x, weight, _t3(stride), _t3(padding))
+    if _last_in_acc is not None:
+        out._ctu_in_acc = _last_in_acc
+        _last_in_acc = None
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------

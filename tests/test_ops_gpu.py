@@ -60,13 +60,14 @@ def cf(t):  # NDHWC -> NCDHW
                                                 (1000, 768, 64, False, 0, True), (130, 16, 16, True, 0, False),
                                                 (64, 3072, 768, True, 1, False), (300, 160, 200, True, 0, False),
                                                 (2000, 256, 384, True, 0, True), (300, 192, 200, True, 1, True),
-                                                (1500, 128, 520, False, 0, False)])
+                                                (1500, 128, 520, False, 0, False), (700, 32, 128, True, 0, True),
+                                                (260, 96, 64, False, 0, False)])
 @pytest.mark.parametrize("gemm", ["dma", "generic"])
 def test_linear(ops, dtype, M, K, N, bias, act, res, gemm):
     """gemm="dma": plain bf16 GEMMs with K % 64 == 0 run on the LDS-DMA kernels (gemm_dma.hip); "generic" pins them to
     the implicit-GEMM kernels (igemm.hip) through the ctu_set_option test hook."""
     from hybrid_ctunet_amd import _lib
-    if gemm == "generic" and (dtype == torch.float32 or K % 64 or N % 64):
+    if gemm == "generic" and (dtype == torch.float32 or K % 32 or N % 64):
         pytest.skip("this case runs on the generic kernels anyway")
     _lib.call("ctu_set_option", b"generic_gemm", 1 if gemm == "generic" else 0)
     ops.USE_W_KN = gemm != "generic"
