@@ -213,7 +213,9 @@ def main():
         s = timer.summary()
         if os.environ.get("CTU_BENCH_SHAPES"):
             print("\n".join(timer.by_shape(int(os.environ["CTU_BENCH_SHAPES"]) if os.environ["CTU_BENCH_SHAPES"].isdigit() and int(os.environ["CTU_BENCH_SHAPES"]) > 1 else 25)), file=sys.stderr, flush=True)
-        dom = max(s, key=lambda k: s[k]["ms"])
+        # dominant kernel = the entry point that carries most of the algorithmic work (the 3x3x3 conv: 80 % of the FLOPs,
+        # SURVEY.md 2.2 row K1); by time it ties with the 360 mostly HBM-bound plain GEMM launches
+        dom = max(s, key=lambda k: s[k]["flops"])
         tot = {k: round(v["ms"] / 2, 3) for k, v in s.items()}
         ach = s[dom]["flops"] / (s[dom]["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

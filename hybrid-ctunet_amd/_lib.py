@@ -127,25 +127,44 @@ def check(rc: int, name: str):
 PROFILER = None  # set by bench.py to an object with .names (set of entry points) and .add(name, args, ev0, ev1)
 
 
+_FN = {}  # entry point name -> bound ctypes function (a step makes ~2 000 calls: keep the per-call Python short)
+
+
+def _fn(name: str):
+    f = _FN.get(name)
+    if f is None:
+        f = _FN[name] = getattr(lib(), name)
+    return f
+
+
 def call(name: str, *args):
     prof = PROFILER
     if prof is not None and name in prof.names:
         # HIP events on the stream the kernel is launched on (torch's current stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(getattr(lib(), name)(*args), name)
+        check(_fn(name)(*args), name)
         e1.record()
         prof.add(name, args, e0, e1)
     else:
-        check(getattr(lib(), name)(*args), name)
+        rc = _fn(name)(*args)
+        if rc != 0:
+            check(rc, name)
 
 
 def ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()  # (ctypes converts the int for a c_void_p parameter)
+
+
+_DEV = None
 
 
 def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw hipStream_t of torch's current stream on this process's device (one process per GPU)."""
+    global _DEV
+    if _DEV is None:
+        _DEV = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(_DEV)
 
 
 def dcode(dtype: torch.dtype) -> int:
