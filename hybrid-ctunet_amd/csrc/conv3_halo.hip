@@ -253,17 +253,17 @@ __global__ __launch_bounds__(256, RD == 2 ? 3 : 2) void conv3_halo_dma_kernel(co
       }
     }
   };
-  auto issue_b = [&](int hc, int s, int slot) {
-    const bf16* base = wf + ((size_t)(((hc >> 1) * 27 + 3 * s) * 2 + (hc & 1)) * p.ntn + nt0) * 512 + lane * 8;
-    unsigned char* dst = smem + RING0 + slot * SBYTES;
+  // weight stage = fragments f = wave, wave + 4, wave + 8 of this wave: per-lane byte offsets inside the stage are
+  // fixed for the kernel, the stage's base address is wave-uniform -> one grouped DMA issue per stage (dma16_group)
+  unsigned bvoff[3];
 #pragma unroll
-    for (int k = 0; k < (SFR + 3) / 4; ++k) {
-      const int f = wave + 4 * k;
-      if (f < SFR) {
-        const int tapi = f / NT, j = f - tapi * NT;
-        dma16(base + (size_t)(tapi * 2 * p.ntn + j) * 512, dst + f * 1024);
-      }
-    }
+  for (int k = 0; k < 3; ++k) {
+    const int f = wave + 4 * k, tapi = f / NT, j = f - tapi * NT;
+    bvoff[k] = (unsigned)(((tapi * 2 * p.ntn + j) * 512 + lane * 8) * 2);
+  }
+  auto issue_b = [&](int hc, int s, int slot) {
+    const bf16* base = wf + ((size_t)(((hc >> 1) * 27 + 3 * s) * 2 + (hc & 1)) * p.ntn + nt0) * 512;
+    dma16_group(b_w, base, bvoff[0], bvoff[1], bvoff[2], smem + RING0 + slot * SBYTES + wave * 1024);
   };
 
   f32x16 acc[2][NT];

@@ -41,3 +41,32 @@ __device__ __forceinline__ void wait_vm_then_barrier_n(int n) {  // n is wave-un
   }
 }
 
+
+// Group of 1..3 DMA instructions sharing one wave-uniform 64-bit base (SGPR pair) with per-lane 32-bit byte offsets,
+// LDS destinations dst0, dst0 + 4096, dst0 + 8192: one M0 save/restore and no 64-bit vector address arithmetic for the
+// group (the per-instruction form above costs ~15 scalar/vector instructions per DMA - as many as the MFMAs it feeds in
+// the short stages of the halo kernel).  The string opens with s_nop 4: the base SGPRs come fresh from
+// v_readfirstlane, and a VMEM instruction reading an SGPR written by a VALU needs 5 wait states, which hipcc does not
+// insert around inline assembly (without it: a memory fault that came and went with the schedule).
+__device__ __forceinline__ void dma16_group(int n, const void* sbase, unsigned v0, unsigned v1, unsigned v2,
+                                            unsigned char* lds_wave_base) {
+  const unsigned dst =
+      __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base);
+  const uint64_t a = (uint64_t)(uintptr_t)sbase;
+  // (readfirstlane returns int: without the unsigned cast a low word with bit 31 set sign-extends over the high word)
+  const uint64_t base = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+                        (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
+  unsigned keep;
+  if (n == 3)
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(v0), "v"(v1), "v"(v2), "s"(dst), "s"(base) : "memory", "scc");
+  else if (n == 2)
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(v0), "v"(v1), "s"(dst), "s"(base) : "memory", "scc");
+  else if (n == 1)
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(v0), "s"(dst), "s"(base) : "memory");
+}

@@ -33,3 +33,20 @@ t1 = time.time()
 torch.cuda.synchronize()
 t2 = time.time()
 print(f"host enqueue {1e3 * (t1 - t0) / n:.1f} ms/step, device-complete {1e3 * (t2 - t0) / n:.1f} ms/step")
+# one step enqueued into an EMPTY queue, forward and backward separately: host time without back-pressure
+for _ in range(3):
+    torch.cuda.synchronize()
+    a = time.time()
+    opt.zero_grad()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = H.LOSSES["ctunet"](model(x), y)
+    b = time.time()
+    torch.cuda.synchronize()
+    c = time.time()
+    loss.backward()
+    opt.step()
+    d = time.time()
+    torch.cuda.synchronize()
+    e = time.time()
+    print(f"forward: host {1e3 * (b - a):.1f} ms (device done after {1e3 * (c - a):.1f}); "
+          f"backward+opt: host {1e3 * (d - c):.1f} ms (device done after {1e3 * (e - c):.1f})")
