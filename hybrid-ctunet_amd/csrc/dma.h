@@ -70,3 +70,29 @@ __device__ __forceinline__ void dma16_group(int n, const void* sbase, unsigned v
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(v0), "s"(dst), "s"(base) : "memory");
 }
+
+// Compile-time-sized variant: N (1, 2 or 4) instructions, LDS destinations STRIDE bytes apart.
+template <int N, int STRIDE>
+__device__ __forceinline__ void dma16_groupN(const void* sbase, const unsigned (&v)[N], unsigned char* lds_wave_base) {
+  static_assert(N == 1 || N == 2 || N == 4, "group size");
+  const unsigned dst =
+      __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base);
+  const uint64_t a = (uint64_t)(uintptr_t)sbase;
+  const uint64_t base = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+                        (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
+  unsigned keep;
+  if constexpr (N == 4)
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6\n\t"
+                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
+                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6\n\t"
+                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %6\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(dst), "s"(base), "n"(STRIDE)
+                 : "memory", "scc");
+  else if constexpr (N == 2)
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+                 "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(v[0]), "v"(v[1]), "s"(dst), "s"(base), "n"(STRIDE) : "memory", "scc");
+  else
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(v[0]), "s"(dst), "s"(base) : "memory");
+}

@@ -125,20 +125,22 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
     const int lda = first ? p.C1 : p.C2;
     const int ka = first ? k0 : k0 - p.C1;
     unsigned char* sa = smem + st * STAGE;
+    // grouped issue (dma.h): wave-uniform 64-bit base of the tile's k slice + per-lane 32-bit byte offsets
+    unsigned va[APW], vb[BPW];
+    const int mrem = p.M - 1 - it.m0;  // tail rows repeat the last row; their outputs are never stored
 #pragma unroll
-    for (int j = 0; j < APW; ++j) {
-      const int m = min(it.m0 + arow[j], p.M - 1);  // tail rows repeat the last row; their outputs are never stored
-      dma16(a + (size_t)m * lda + ka + aslot[j] * 8, sa + (APW * wave + j) * 1024);
-    }
+    for (int j = 0; j < APW; ++j) va[j] = (unsigned)((min(arow[j], mrem) * lda + aslot[j] * 8) * 2);
+    dma16_groupN<APW, 1024>(a + (size_t)it.m0 * lda + ka, va, sa + APW * wave * 1024);
+    if constexpr (BT) {
 #pragma unroll
-    for (int j = 0; j < BPW; ++j) {
-      if constexpr (BT) {
-        const int n = min(it.n0 + bslot[j], p.N - 8);  // columns past N feed only outputs that are never stored
-        dma16(p.w + (size_t)(k0 + brow[j]) * p.N + n, sa + A_BYTES + (BPW * wave + j) * 1024);
-      } else {
-        const int n = min(it.n0 + brow[j], p.N - 1);
-        dma16(p.w + (size_t)n * p.K + k0 + bslot[j] * 8, sa + A_BYTES + (BPW * wave + j) * 1024);
-      }
+      for (int j = 0; j < BPW; ++j)  // columns past N feed only outputs that are never stored
+        vb[j] = (unsigned)((brow[j] * p.N + min(it.n0 + bslot[j], p.N - 8)) * 2);
+      dma16_groupN<BPW, 1024>(p.w + (size_t)k0 * p.N, vb, sa + A_BYTES + BPW * wave * 1024);
+    } else {
+      const int nrem = p.N - 1 - it.n0;
+#pragma unroll
+      for (int j = 0; j < BPW; ++j) vb[j] = (unsigned)((min(brow[j], nrem) * p.K + bslot[j] * 8) * 2);
+      dma16_groupN<BPW, 1024>(p.w + (size_t)it.n0 * p.K + k0, vb, sa + A_BYTES + BPW * wave * 1024);
     }
   };
 
@@ -441,8 +443,27 @@ __global__ __launch_bounds__(256, (R * (TN + TC) * 128 > 80 * 1024) ? 1 : 2) voi
     qld[q] = first ? a.C1 : a.C2;
     qcol[q] = first ? c : c - a.C1;
   }
+  // full stages take the grouped issue (dma.h): the per-lane byte offsets inside a stage never change, only the
+  // wave-uniform base advances by 64 rows; the last (partial) stage and two-source Q operands keep the per-lane form
+  unsigned vpo[PI], vqo[QI];
+#pragma unroll
+  for (int q = 0; q < PI; ++q) {
+    const int ins = wave + 4 * q;
+    vpo[q] = (unsigned)((((ins & 3) * 16 + (lane >> 2)) * a.ldp + pcol[q]) * 2);
+  }
+#pragma unroll
+  for (int q = 0; q < QI; ++q) {
+    const int ins = wave + 4 * q;
+    vqo[q] = (unsigned)((((ins & 3) * 16 + (lane >> 2)) * a.C1 + qcol[q]) * 2);
+  }
+  const bool groupable = a.C2 == 0;
   auto issue = [&](int mb, int st) {
     unsigned char* dst = smem + st * STAGE;
+    if (groupable && mb + BKM <= m_end) {
+      dma16_groupN<PI, 4096>(a.p + (size_t)mb * a.ldp, vpo, dst + wave * 1024);
+      dma16_groupN<QI, 4096>(a.q1 + (size_t)mb * a.C1, vqo, dst + NP * PANEL + wave * 1024);
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < PI; ++q) {
       const int ins = wave + 4 * q;
