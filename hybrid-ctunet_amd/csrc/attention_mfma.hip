@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const T* __restrict_
   __syncthreads();
 
   const int ktiles = (c.ntok + 31) / 32;
-  for (int qt = wave; qt < ktiles; qt += 4) {
+  for (int qt = wave + 4 * blockIdx.y; qt < ktiles; qt += 4 * gridDim.y) {  // blockIdx.y: split of the tile loop
     const int q = qt * 32 + r;
     const bool qok = q < c.ntok;
     typename Mma<T>::Frag fq[DH / 16];
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(const T* __restric
   __syncthreads();
 
   const int ktiles = (c.ntok + 31) / 32;
-  for (int qt = wave; qt < ktiles; qt += 4) {
+  for (int qt = wave + 4 * blockIdx.y; qt < ktiles; qt += 4 * gridDim.y) {  // blockIdx.y: split of the tile loop
     const int q = qt * 32 + r;
     const bool qok = q < c.ntok;
     typename Mma<T>::Frag fq[DH / 16], fg[DH / 16], fo[DH / 16];
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(const T* __restri
   __syncthreads();
 
   const int ktiles = (c.ntok + 31) / 32;
-  for (int kt = wave; kt < ktiles; kt += 4) {
+  for (int kt = wave + 4 * blockIdx.y; kt < ktiles; kt += 4 * gridDim.y) {  // blockIdx.y: split of the tile loop
     const int key = kt * 32 + r;
     const bool kok = key < c.ntok;
     typename Mma<T>::Frag fk[DH / 16], fv[DH / 16];
@@ -425,16 +425,32 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(const T* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// grid: x = (group, head); y = split of the 32-row tile loop.  The ViT trunk has 2 x 12 (group, head) pairs with 14
+// tiles each: without the split 24 workgroups serve 256 CUs.  Every workgroup stages the whole K/V (or Q/dO) of its
+// pair; its waves then take tiles wave + 4 y, + 4 gridDim.y, ...; outputs are rows of disjoint tiles.
+static dim3 attn_grid(const AttnCtx& c) {
+  const int pairs = c.groups * c.g.heads;
+  const int ktiles = (c.ntok + 31) / 32;
+  int ys = 1;
+  if (pairs < 256) {
+    ys = (512 + pairs - 1) / pairs;
+    const int maxy = (ktiles + 3) / 4;
+    if (ys > maxy) ys = maxy;
+    if (ys < 1) ys = 1;
+  }
+  return dim3(pairs, ys);
+}
+
 template <typename T, int DH, int KT>
 static int launch_fwd(const void* qkv, const float* bias, void* out, float* lse, const AttnCtx& c, hipStream_t s) {
-  hipLaunchKernelGGL((attn_mfma_fwd_kernel<T, DH, KT>), dim3(c.groups * c.g.heads), dim3(256), 0, s, (const T*)qkv, bias,
+  hipLaunchKernelGGL((attn_mfma_fwd_kernel<T, DH, KT>), attn_grid(c), dim3(256), 0, s, (const T*)qkv, bias,
                      (T*)out, lse, c);
   return ctu_check_launch("attn_mfma_fwd");
 }
 template <typename T, int DH, int KT>
 static int launch_bwd(const void* qkv, const float* bias, const void* out, const void* dout, const float* lse, void* dqkv,
                       float* dbias, const AttnCtx& c, hipStream_t s) {
-  const dim3 grid(c.groups * c.g.heads);
+  const dim3 grid = attn_grid(c);
   hipLaunchKernelGGL((attn_mfma_bwd_q_kernel<T, DH, KT>), grid, dim3(256), 0, s, (const T*)qkv, bias, (const T*)out,
                      (const T*)dout, lse, (T*)dqkv, dbias, c);
   hipLaunchKernelGGL((attn_mfma_bwd_kv_kernel<T, DH, KT>), grid, dim3(256), 0, s, (const T*)qkv, bias, (const T*)out,
