@@ -166,7 +166,6 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float* stage = reinterpret_cast<float*>(smem + R * STAGE) + wave * 16 * EPI_LD;
   bf16* out = reinterpret_cast<bf16*>(p.out);
 
   if (vid >= p.nwork) return;
@@ -261,76 +260,82 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) { const float v = acc[i][j][e]; rs1[j] += v; rs2[j] += v * v; }
       }
-      // epilogue through a wave-private 16 x 32 fp32 patch (outside the DMA ring: the next tile is already in flight).
-      // The residual vectors of all 2 MI NJ patches are requested FIRST: loaded patch by patch they are 2 MI NJ
-      // dependent global round trips per tile (most of a short trunk GEMM's life).
-      const int erow = lane >> 2, ecv = lane & 3;
+      // epilogue through a wave-private fp32 patch of PR rows x the wave's WN columns (outside the DMA ring: the next
+      // tile is already in flight): every store instruction then writes whole rows of the wave's column range
+      // (128 B for WN = 64) instead of 64-B halves of a line.  The residual vectors of all MI NR patches are requested
+      // FIRST: loaded patch by patch they are dependent global round trips (most of a short trunk GEMM's life).
+      constexpr int PR = 512 / WN;    // patch rows: 16 (WN = 32) or 8 (WN = 64)
+      constexpr int PLD = WN + 4;
+      constexpr int NR = 32 / PR;     // patches per 32-row MFMA tile
+      constexpr int RPR = 16 / NR;    // accumulator registers per patch
+      constexpr int VPRW = WN / 8;    // 8-column vectors per patch row
+      static_assert(4 * PR * PLD * 4 <= EPI_BYTES, "patch must fit the epilogue region");
+      const int erow = lane / VPRW, ecv = lane % VPRW;
       const bool want_res = p.ep.residual != nullptr && p.splitk <= 1;
-      bf16x8 resv[MI * NJ * 2];
+      bf16x8 resv[MI * NR];
       if (want_res) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j)
+          for (int t = 0; t < NR; ++t) {
+            const int m = cur.m0 + wm * WM + i * 32 + t * PR + erow, n = cur.n0 + wn * WN + ecv * 8;
+            bf16x8 v;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-              const int m = cur.m0 + wm * WM + i * 32 + half * 16 + erow, n = cur.n0 + wn * WN + j * 32 + ecv * 8;
-              bf16x8 v;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
-              if (m < p.M && n < p.N) {
-                bf16* dst;
-                const size_t off = epilogue_offset(p.ep, out, m, n, dst);
-                v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.ep.residual) + off);
-              }
-              resv[(i * NJ + j) * 2 + half] = v;
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+            if (m < p.M && n < p.N) {
+              bf16* dst;
+              const size_t off = epilogue_offset(p.ep, out, m, n, dst);
+              v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.ep.residual) + off);
             }
+            resv[i * NR + t] = v;
+          }
       }
+      float* patch = reinterpret_cast<float*>(smem + R * STAGE) + wave * (EPI_BYTES / 16);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int t = 0; t < NR; ++t) {
 #pragma unroll
-          for (int half = 0; half < 2; ++half) {
+          for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-              stage[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_LD + r] = acc[i][j][8 * half + e];
-            __builtin_amdgcn_wave_barrier();
-            const int mb = cur.m0 + wm * WM + i * 32 + half * 16;
-            const int nb = cur.n0 + wn * WN + j * 32;
-            if (p.splitk > 1) {
+            for (int ee = 0; ee < RPR; ++ee)
+              patch[((ee & 3) + 8 * (ee >> 2) + 4 * h) * PLD + j * 32 + r] = acc[i][j][RPR * t + ee];
+          __builtin_amdgcn_wave_barrier();
+          const int mb = cur.m0 + wm * WM + i * 32 + t * PR;
+          const int nb = cur.n0 + wn * WN;
+          if (p.splitk > 1) {
 #pragma unroll
-              for (int q = 0; q < 8; ++q) {
-                const int idx = lane + 64 * q;
-                const int row = idx >> 5, col = idx & 31;
-                if (mb + row < p.M && nb + col < p.N)
-                  atomicAdd(p.ws + (size_t)(mb + row) * p.N + nb + col, stage[row * EPI_LD + col]);
-              }
-            } else {
-              const int m = mb + erow, n = nb + ecv * 8;
-              if (m < p.M && n < p.N) {
-                float x[8];
-                load8(&stage[erow * EPI_LD + ecv * 8], x);
-                if (p.ep.bias) {
-#pragma unroll
-                  for (int e = 0; e < 8; ++e) x[e] += p.ep.bias[n + e];
-                }
-                if (p.ep.act == 1) {
-#pragma unroll
-                  for (int e = 0; e < 8; ++e) x[e] = gelu_erf(x[e]);
-                }
-                if (want_res) {
-                  const bf16x8 rv = resv[(i * NJ + j) * 2 + half];
-#pragma unroll
-                  for (int e = 0; e < 8; ++e) x[e] += (float)rv[e];
-                }
-                bf16* dst;
-                const size_t off = epilogue_offset(p.ep, out, m, n, dst);
-                store8(dst + off, x);
-              }
+            for (int q = 0; q < 8; ++q) {
+              const int idx = lane + 64 * q;
+              const int row = idx / WN, col = idx % WN;
+              if (mb + row < p.M && nb + col < p.N)
+                atomicAdd(p.ws + (size_t)(mb + row) * p.N + nb + col, patch[row * PLD + col]);
             }
-            __builtin_amdgcn_wave_barrier();
+          } else {
+            const int m = mb + erow, n = nb + ecv * 8;
+            if (m < p.M && n < p.N) {
+              float x[8];
+              load8(&patch[erow * PLD + ecv * 8], x);
+              if (p.ep.bias) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] += p.ep.bias[n + e];
+              }
+              if (p.ep.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = gelu_erf(x[e]);
+              }
+              if (want_res) {
+                const bf16x8 rv = resv[i * NR + t];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] += (float)rv[e];
+              }
+              bf16* dst;
+              const size_t off = epilogue_offset(p.ep, out, m, n, dst);
+              store8(dst + off, x);
+            }
           }
+          __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
