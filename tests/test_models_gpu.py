@@ -153,6 +153,9 @@ def _run_model(H, golden_dir, name, precision):
     (err of the HIP path vs the reference run in fp64, err of the fp32 reference vs the same fp64 value,
      err of the HIP path vs the fp32 reference)."""
     from oracle import ctunet_oracle as O
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     kind, depth = MODELS[name]
     z = _npz(golden_dir, f"model_{name}.npz")
     z64 = _npz(golden_dir, f"model_{name}_f64.npz")

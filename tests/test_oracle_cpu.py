@@ -9,7 +9,21 @@ import torch
 
 from oracle import ctunet_oracle as O
 
-torch.set_num_threads(os.cpu_count() or 8)
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _cpu_threads():
+    """Use the cores this process may actually run on (at most 16) for the oracle - and only while THESE tests run: a
+    module-level torch.set_num_threads(os.cpu_count()) also hit the GPU tests collected in the same session, where the
+    box reports every host core but the job owns 16 (the whole GPU suite took 15 minutes of thrashing instead of 1)."""
+    before = torch.get_num_threads()
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 8
+    torch.set_num_threads(max(1, min(16, n)))
+    yield
+    torch.set_num_threads(before)
 
 
 def _npz(golden_dir, name):
