@@ -31,7 +31,7 @@ class Epilogue(C.Structure):
     _fields_ = [("bias", _vp), ("residual", _vp), ("act", _i32), ("ldc", _i32), ("out2", _vp), ("n_split", _i32),
                 ("ldc2", _i32), ("scatter", _i32), ("n_per_tap", _i32), ("sc_D", _i32), ("sc_H", _i32),
                 ("sc_W", _i32), ("sc_kd", _i32), ("sc_kh", _i32), ("sc_kw", _i32), ("splitk", _i32),
-                ("w_kn", _i32), ("splitk_ws", _vp), ("in_acc", _vp), ("in_rows", _i32), ("reserved_", _i32)]
+                ("w_kn", _i32), ("splitk_ws", _vp), ("in_acc", _vp), ("in_rows", _i32), ("reserved_", _i32), ("pre_out", _vp)]
 
 
 class AttnGeom(C.Structure):

@@ -320,6 +320,7 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] += p.ep.bias[n + e];
               }
+              if (p.ep.pre_out) store8(reinterpret_cast<bf16*>(p.ep.pre_out) + (size_t)m * p.ep.ldc + n, x);
               if (p.ep.act == 1) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] = gelu_erf(x[e]);

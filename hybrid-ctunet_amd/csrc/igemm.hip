@@ -289,6 +289,7 @@ template <> struct NtDma<bf16> {
     q.M = p.M; q.N = g->N; q.K = K; q.C1 = g->C1; q.C2 = g->C2;
     q.w_kn = ep->w_kn;
     if (q.w_kn && (g->C2 > 0 || ep->scatter)) return false;
+    if (ep->pre_out && (ep->scatter || ep->n_split > 0 || (ep->splitk > 1 && ep->splitk_ws))) return false;
     q.in_acc = ep->in_acc;
     q.in_rows = ep->in_rows;
     if (q.in_acc && (ep->in_rows <= 0 || ep->in_rows % 128 != 0 || p.M % ep->in_rows != 0 || ep->scatter ||
@@ -320,8 +321,8 @@ static int launch_nt(const void* a1, const void* a2, const void* w, void* out, c
   p.ws = ep->splitk_ws;
   if (NtDma<T>::launch(a1, a2, w, out, g, ep, p, stream)) {
     // plain bf16 GEMM on the LDS-DMA kernel (gemm_dma.hip); p.splitk holds the split it used
-  } else if (ep->w_kn || ep->in_acc) {
-    ctu_set_error("igemm_nt: w_kn / in_acc need a plain bf16 GEMM with K %% 64 == 0 (see ctu_epilogue)");
+  } else if (ep->w_kn || ep->in_acc || ep->pre_out) {
+    ctu_set_error("igemm_nt: w_kn / in_acc / pre_out need a plain bf16 GEMM with K %% 32 == 0 (see ctu_epilogue)");
     return CTU_ERR_ARG;
   } else if (g->N <= 64) {
     p.tiles_n = (g->N + 63) / 64;

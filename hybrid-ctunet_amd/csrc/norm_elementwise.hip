@@ -681,14 +681,32 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, co
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    if (rl < rlanes && cg < ncg)
-      for (int64_t m = m_begin + rl; m < m_end; m += rlanes) {
+    if (rl < rlanes && cg < ncg) {
+      int64_t m = m_begin + rl;
+      // four rows in flight per thread: a narrow matrix runs few workgroups (see ctu_colsum), so latency must be hidden
+      // inside the thread
+      for (; m + 3 * (int64_t)rlanes < m_end; m += 4 * (int64_t)rlanes) {
+        float v0[8], v1[8], v2[8], v3[8];
+        load8(x + (size_t)m * ld + cg * 8, v0);
+        load8(x + (size_t)(m + rlanes) * ld + cg * 8, v1);
+        load8(x + (size_t)(m + 2 * rlanes) * ld + cg * 8, v2);
+        load8(x + (size_t)(m + 3 * rlanes) * ld + cg * 8, v3);
+        float s0 = 1.f, s1 = 1.f, s2 = 1.f, s3 = 1.f;
+        if (row_scale) {
+          s0 = (float)row_scale[m]; s1 = (float)row_scale[m + rlanes];
+          s2 = (float)row_scale[m + 2 * rlanes]; s3 = (float)row_scale[m + 3 * rlanes];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (s0 * v0[e] + s1 * v1[e]) + (s2 * v2[e] + s3 * v3[e]);
+      }
+      for (; m < m_end; m += rlanes) {
         float v[8];
         load8(x + (size_t)m * ld + cg * 8, v);
         const float sc = row_scale ? (float)row_scale[m] : 1.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = fmaf(sc, v[e], acc[e]);
       }
+    }
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[tid * 8 + e] = acc[e];
@@ -971,19 +989,20 @@ __global__ __launch_bounds__(256) void im2col_cin1_kernel(const bf16* __restrict
     const int od = t % g.Do;
     const int b = t / g.Do;
     bf16x8 v;
+    // first tap of the group decomposed once, the next seven by increment with carry
+    int tw = k0 % g.kw;
+    int tq = k0 / g.kw;
+    int th = tq % g.kh, td = tq / g.kh;
+    const int bd = od * g.sd - g.pd, bh = oh * g.sh - g.ph, bw = ow * g.sw - g.pw;
+    const bf16* xb = x + (size_t)b * g.Di * g.Hi * g.Wi;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int k = k0 + j;
-      float val = 0.f;
-      if (k < taps) {
-        const int tw = k % g.kw;
-        const int tq = k / g.kw;
-        const int th = tq % g.kh, td = tq / g.kh;
-        const int id = od * g.sd - g.pd + td, ih = oh * g.sh - g.ph + th, iw = ow * g.sw - g.pw + tw;
-        if ((unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi)
-          val = (float)x[(((size_t)b * g.Di + id) * g.Hi + ih) * g.Wi + iw];
-      }
-      v[j] = (bf16)val;
+      bf16 val = (bf16)0.f;
+      const int id = bd + td, ih = bh + th, iw = bw + tw;
+      if (k0 + j < taps && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi)
+        val = xb[((size_t)id * g.Hi + ih) * g.Wi + iw];
+      v[j] = val;
+      if (++tw == g.kw) { tw = 0; if (++th == g.kh) { th = 0; ++td; } }
     }
     *reinterpret_cast<bf16x8*>(P + m * kpad + k0) = v;
   }

@@ -173,8 +173,9 @@ def _splitk_workspace(device, n):
 
 
 def _epi(ldc, bias=None, residual=None, act=0, out2=None, n_split=0, ldc2=0, scatter=None, splitk_ws=None,
-         splitk=1, w_kn=0, in_acc=None, in_rows=0) -> Epilogue:
+         splitk=1, w_kn=0, in_acc=None, in_rows=0, pre_out=None) -> Epilogue:
     e = Epilogue()
+    e.pre_out = ptr(pre_out)
     e.w_kn = w_kn
     e.in_acc = ptr(in_acc)
     e.in_rows = in_rows
@@ -226,13 +227,14 @@ def _igemm_tn(p, ldp, q1, q2, dw, g: Geom, bias_grad=None):
          stream())
 
 
-def _plain_gemm(x, w, out, M, K, N, bias=None, residual=None, act=0, w_kn=0, in_acc=None, in_rows=0):
+def _plain_gemm(x, w, out, M, K, N, bias=None, residual=None, act=0, w_kn=0, in_acc=None, in_rows=0, pre_out=None):
     """out[M,N] = act(x[M,K] @ w[N,K]^T + bias) + residual, with split-K when there are few tiles and a long K."""
-    sk = 1 if in_acc is not None else _splitk_for(M, N, K, dma=x.dtype == torch.bfloat16 and K % 32 == 0)
+    sk = 1 if (in_acc is not None or pre_out is not None) else \
+        _splitk_for(M, N, K, dma=x.dtype == torch.bfloat16 and K % 32 == 0)
     ws = _splitk_workspace(x.device, M * N) if sk > 1 else None
     _igemm_nt(x, None, w, out, _plain_geom(M, K, N),
               _epi(N, bias=bias, residual=residual, act=act, splitk_ws=ws, splitk=sk, w_kn=w_kn, in_acc=in_acc,
-                   in_rows=in_rows))
+                   in_rows=in_rows, pre_out=pre_out))
 
 
 USE_W_KN = True  # tests clear this together with the "generic_gemm" hook (the generic kernels need W transposed)
@@ -271,7 +273,11 @@ class LinearFn(torch.autograd.Function):
         wf = _linear_weight(weight, w2, x.dtype)
         pre = None
         out = torch.empty((*x.shape[:-1], N), dtype=x.dtype, device=x.device)
-        if act == 1 and any(ctx.needs_input_grad[:3]):
+        if act == 1 and any(ctx.needs_input_grad[:3]) and USE_W_KN and x.dtype == torch.bfloat16 and K % 32 == 0:
+            # GELU in the GEMM epilogue, the pre-activation (for GELU') stored alongside: no separate activation pass
+            pre = torch.empty_like(out)
+            _plain_gemm(x, wf, out, M, K, N, bias=bias, residual=residual, act=1, pre_out=pre)
+        elif act == 1 and any(ctx.needs_input_grad[:3]):
             # keep the pre-activation for GELU'
             pre = torch.empty_like(out)
             _plain_gemm(x, wf, pre, M, K, N, bias=bias)

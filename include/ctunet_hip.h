@@ -90,6 +90,9 @@ typedef struct ctu_epilogue {
   double* in_acc;
   int32_t in_rows;
   int32_t reserved_;
+  /* act == 1 only, same restrictions as in_acc: also store the PRE-activation (x + bias) to pre_out [M][ldc] - what
+   * the GELU backward needs - so training needs no separate activation pass over the hidden tensor. */
+  void* pre_out;
 } ctu_epilogue;
 
 /* K1/K3/K5/K2/K4 forward and data-gradient:  out[m][n] = sum_tap sum_c A[gather(m,tap)][c] * W[tap][n][c]

@@ -39,7 +39,7 @@ def test_ctypes_struct_layouts_match_header():
     assert e.bias.offset == 0 and e.residual.offset == 8 and e.act.offset == 16 and e.ldc.offset == 20
     assert e.out2.offset == 24 and e.n_split.offset == 32 and e.sc_kw.offset == 32 + 4 * 9
     assert e.splitk.offset == 72 and e.w_kn.offset == 76 and e.splitk_ws.offset == 80 and e.in_acc.offset == 88
-    assert e.in_rows.offset == 96 and ctypes.sizeof(e) == 104
+    assert e.in_rows.offset == 96 and e.pre_out.offset == 104 and ctypes.sizeof(e) == 112
 
 
 @pytest.mark.parametrize("kind,depth,man", [("ctunet", 101, "ctunet101"), ("cunet", 101, "cunet101"),
