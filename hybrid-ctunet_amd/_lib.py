@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libctunet_hip.so")
 SOURCES = ["igemm.hip", "gemm_dma.hip", "conv3_halo.hip", "norm_elementwise.hip", "attention.hip", "attention_mfma.hip",
-           "loss_optim.hip", "mma.h", "dma.h", "gemm_dma.h", "attn_common.h", "common.h"]
+           "loss_optim.hip", "infer.hip", "mma.h", "dma.h", "gemm_dma.h", "attn_common.h", "common.h"]
 
 CTU_F32, CTU_BF16 = 0, 1
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -75,6 +75,9 @@ _SIGS = {
     "ctu_dicece_bwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp] + [_i32] * 8 + [_vp, _f32, _f32, _f32, _vp, _vp, _vp],
     "ctu_adamw": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, C.POINTER(_i64), _i32, _vp],
     "ctu_cast": [_vp, _i32, _vp, _i32, _i64, _vp],
+    "ctu_sw_accumulate": [_i32, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp] + [_i32] * 11 + [_vp],
+    "ctu_sw_normalize": [_vp, _vp, _i32, _i32, _i64, _vp],
+    "ctu_hybrid_argmax": [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp],
     "ctu_set_option": [C.c_char_p, _i32],
 }
 EXPORTED = sorted(list(_SIGS) + ["ctu_abi_version", "ctu_last_error"])

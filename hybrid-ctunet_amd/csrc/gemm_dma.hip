@@ -290,6 +290,17 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
             resv[i * NR + t] = v;
           }
       }
+      // this lane's 8 bias values: its columns are the same in every patch of the tile - one load, not one per patch
+      float bv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+      if (p.ep.bias && p.splitk <= 1) {
+        const int n = cur.n0 + wn * WN + ecv * 8;
+        if (n < p.N) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bv[e] = p.ep.bias[n + e];
+        }
+      }
       float* patch = reinterpret_cast<float*>(smem + R * STAGE) + wave * (EPI_BYTES / 16);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -316,10 +327,8 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
             if (m < p.M && n < p.N) {
               float x[8];
               load8(&patch[erow * PLD + ecv * 8], x);
-              if (p.ep.bias) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] += p.ep.bias[n + e];
-              }
+              for (int e = 0; e < 8; ++e) x[e] += bv[e];
               if (p.ep.pre_out) store8(reinterpret_cast<bf16*>(p.ep.pre_out) + (size_t)m * p.ep.ldc + n, x);
               if (p.ep.act == 1) {
 #pragma unroll

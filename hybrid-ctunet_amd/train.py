@@ -236,6 +236,23 @@ class FusedAdamW:
     def zero_grad(self, set_to_none: bool = False):
         self.flat.zero_grad()
 
+    def state_dict(self):
+        """Flat optimizer state (for checkpoint.save_checkpoint): step count, hyper-parameters and the two moment buffers
+        in FlatParams order together with the parameter shapes that define that order."""
+        return {"step": self.step_count, "param_groups": [dict(g) for g in self.param_groups],
+                "shapes": [tuple(p.shape) for p in self.flat.params], "offsets": list(self.flat.offsets),
+                "exp_avg": self.m.detach().cpu(), "exp_avg_sq": self.v.detach().cpu()}
+
+    def load_state_dict(self, sd):
+        if [tuple(s) for s in sd["shapes"]] != [tuple(p.shape) for p in self.flat.params]:
+            raise ValueError("optimizer state was saved for a different parameter order / model")
+        self.step_count = int(sd["step"])
+        self.param_groups = [dict(g) for g in sd["param_groups"]]
+        g0 = self.param_groups[0]
+        self.lr, self.betas, self.eps, self.weight_decay = g0["lr"], tuple(g0["betas"]), g0["eps"], g0["weight_decay"]
+        self.m.copy_(sd["exp_avg"])
+        self.v.copy_(sd["exp_avg_sq"])
+
     def freeze_skip_ranges(self):
         """After one real backward: remember which parameters never receive a gradient, so later steps (e.g. replayed
         from a HIP graph, where Python hooks do not run) skip the same ranges."""

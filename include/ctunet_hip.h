@@ -268,6 +268,21 @@ int ctu_dicece_bwd(ctu_dtype dtype, const void* logits, int32_t ldl, const float
 int ctu_adamw(float* p, const float* g, float* m, float* v, void* mirror_bf16, int64_t n, float lr, float beta1, float beta2,
               float eps, float weight_decay, int32_t step, const int64_t* skip_host, int32_t n_skip,
               ctu_stream_t stream);
+/* ---- inference-side callers of forward ----------------------------------------------------
+ * Sliding-window accumulation (trainer_CTUNet.py:538-548, trainer_CUNet.py:386-392): for one window whose prediction
+ * element (c,d,h,w) is logits[c*sc + d*sd + h*sh + w*sw] (dtype fp32 or bf16, any strides - the models return
+ * channels-last views), out[b][c][d0+d][h0+h][w0+w] += importance[d][h][w] * logits and, when count != NULL,
+ * count[b][d0+d][h0+h][w0+w] += importance (one weight map serves every class).  out fp32 [B][C][D][H][W]. */
+int ctu_sw_accumulate(ctu_dtype dtype, const void* logits, int64_t sc, int64_t sd, int64_t sh, int64_t sw,
+                      const float* importance, float* out, float* count, int32_t C, int32_t rd, int32_t rh, int32_t rw,
+                      int32_t b, int32_t d0, int32_t h0, int32_t w0, int32_t D, int32_t H, int32_t W, ctu_stream_t stream);
+/* out[b][c][s] /= count[b][s]  (trainer_CTUNet.py:547-548) */
+int ctu_sw_normalize(float* out, const float* count, int32_t B, int32_t C, int64_t S, ctu_stream_t stream);
+/* Hybrid complementation (test_CTUNet_final.py:545-551): labels of softmax(p1), softmax(p2) and of their average, p1/p2
+ * fp32 [C][S], C <= 32; labels1 / labels2 may be NULL.  First maximum wins (torch.argmax). */
+int ctu_hybrid_argmax(const float* p1, const float* p2, int32_t C, int64_t S, int64_t* labels1, int64_t* labels2,
+                      int64_t* labels_hybrid, ctu_stream_t stream);
+
 /* fp32 <-> dtype casts and fills */
 int ctu_cast(const void* src, ctu_dtype src_dtype, void* dst, ctu_dtype dst_dtype, int64_t n, ctu_stream_t stream);
 
