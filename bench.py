@@ -203,6 +203,10 @@ def main():
     final_loss = loss.item()
 
     roofline = None
+    if not a.no_roofline and rank != 0:
+        for _ in range(2):  # the instrumented steps below contain the gradient all-reduce: every rank takes part
+            step()
+        torch.cuda.synchronize()
     if not a.no_roofline and rank == 0:
         timer = KernelTimer()
         _lib.PROFILER = timer
