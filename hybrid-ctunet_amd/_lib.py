@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libctunet_hip.so")
 SOURCES = ["igemm.hip", "gemm_dma.hip", "conv3_halo.hip", "norm_elementwise.hip", "attention.hip", "attention_mfma.hip",
-           "loss_optim.hip", "infer.hip", "mma.h", "dma.h", "gemm_dma.h", "attn_common.h", "common.h"]
+           "loss_optim.hip", "infer.hip", "dropout.hip", "philox.h", "mma.h", "dma.h", "gemm_dma.h", "attn_common.h", "common.h"]
 
 CTU_F32, CTU_BF16 = 0, 1
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -66,6 +66,10 @@ _SIGS = {
     "ctu_add_bcast": [_i32, _vp, _vp, _vp, _i64, _i32, _i64, _vp],
     "ctu_attn_fwd": [_i32, _vp, _vp, _vp, _vp, C.POINTER(AttnGeom), _vp],
     "ctu_attn_bwd": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(AttnGeom), _vp],
+    "ctu_attn_fwd_dropout": [_i32, _vp, _vp, _vp, _vp, C.POINTER(AttnGeom), _f32, C.c_uint64, C.c_uint64, _vp],
+    "ctu_attn_bwd_dropout": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(AttnGeom), _f32, C.c_uint64, C.c_uint64, _vp],
+    "ctu_dropout": [_i32, _vp, _vp, _vp, _i64, _f32, C.c_uint64, C.c_uint64, _vp],
+    "ctu_attn_dropout_mask": [_vp, _i32, _i32, _f32, C.c_uint64, C.c_uint64, _vp],
     "ctu_pwa_fwd": [_i32, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "ctu_pwa_bwd": [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "ctu_patchify": [_i32, _vp, _vp] + [_i32] * 7 + [_vp],

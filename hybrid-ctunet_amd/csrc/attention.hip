@@ -375,13 +375,19 @@ static int make_ctx(const ctu_attn_geom* g, AttnCtx* c) {
     c->reloff = (g->win - 1) * (c->relm * c->relm + c->relm + 1);
   }
   CTU_REQUIRE((int64_t)c->groups * g->heads < (1ll << 31), "too many attention groups");
+  c->drop.thr16 = 0; c->drop.scale = 1.f; c->drop.k0 = c->drop.k1 = c->drop.site = 0;
   return CTU_OK;
 }
 
-extern "C" int ctu_attn_fwd(ctu_dtype dtype, const void* qkv, const float* bias_table, void* out, float* lse,
-                            const ctu_attn_geom* g, ctu_stream_t stream) {
+static int set_drop(AttnCtx* c, float p, uint64_t seed, uint64_t offset) {
+  CTU_REQUIRE(ctu_make_drop_ctx(p, seed, offset, &c->drop) == 0, "attention dropout: p must be in [0, 1)");
+  return CTU_OK;
+}
+static int attn_fwd_impl(ctu_dtype dtype, const void* qkv, const float* bias_table, void* out, float* lse,
+                         const ctu_attn_geom* g, float p, uint64_t seed, uint64_t offset, ctu_stream_t stream) {
   AttnCtx c;
   if (int rc = make_ctx(g, &c)) return rc;
+  if (int rc = set_drop(&c, p, seed, offset)) return rc;
   CTU_REQUIRE(qkv && out && lse, "null pointer");
   CTU_REQUIRE(!bias_table || g->part != 0, "bias table needs a window partition");
   dim3 grid(c.groups * g->heads, (c.ntok + 31) / 32);
@@ -390,6 +396,7 @@ extern "C" int ctu_attn_fwd(ctu_dtype dtype, const void* qkv, const float* bias_
     const int rc = attn_mfma_fwd(dtype, qkv, bias_table, out, lse, c, s);
     if (rc >= 0) return rc;
   }
+  CTU_REQUIRE(c.drop.thr16 == 0, "attention dropout runs on the MFMA kernels only (bf16, or fp32 with <= 224 tokens)");
 #define ATT_FWD(T, DH) \
   hipLaunchKernelGGL((attn_fwd_kernel<T, DH>), grid, dim3(256), 0, s, (const T*)qkv, bias_table, (T*)out, lse, c)
   if (g->dh == 32) { CTU_DISPATCH(dtype, ATT_FWD(float, 32), ATT_FWD(bf16, 32)); }
@@ -398,11 +405,21 @@ extern "C" int ctu_attn_fwd(ctu_dtype dtype, const void* qkv, const float* bias_
   return ctu_check_launch("attn_fwd");
 }
 
-extern "C" int ctu_attn_bwd(ctu_dtype dtype, const void* qkv, const float* bias_table, const void* out,
-                            const void* dout, const float* lse, void* dqkv, float* dbias, const ctu_attn_geom* g,
-                            ctu_stream_t stream) {
+extern "C" int ctu_attn_fwd(ctu_dtype dtype, const void* qkv, const float* bias_table, void* out, float* lse,
+                            const ctu_attn_geom* g, ctu_stream_t stream) {
+  return attn_fwd_impl(dtype, qkv, bias_table, out, lse, g, 0.f, 0, 0, stream);
+}
+extern "C" int ctu_attn_fwd_dropout(ctu_dtype dtype, const void* qkv, const float* bias_table, void* out, float* lse,
+                                    const ctu_attn_geom* g, float p, uint64_t seed, uint64_t offset, ctu_stream_t stream) {
+  return attn_fwd_impl(dtype, qkv, bias_table, out, lse, g, p, seed, offset, stream);
+}
+
+static int attn_bwd_impl(ctu_dtype dtype, const void* qkv, const float* bias_table, const void* out, const void* dout,
+                         const float* lse, void* dqkv, float* dbias, const ctu_attn_geom* g, float p, uint64_t seed,
+                         uint64_t offset, ctu_stream_t stream) {
   AttnCtx c;
   if (int rc = make_ctx(g, &c)) return rc;
+  if (int rc = set_drop(&c, p, seed, offset)) return rc;
   CTU_REQUIRE(qkv && out && dout && lse && dqkv, "null pointer");
   CTU_REQUIRE((bias_table != nullptr) == (dbias != nullptr), "bias_table and dbias must be given together");
   CTU_REQUIRE(!bias_table || g->part != 0, "bias table needs a window partition");
@@ -412,6 +429,7 @@ extern "C" int ctu_attn_bwd(ctu_dtype dtype, const void* qkv, const float* bias_
     const int rc = attn_mfma_bwd(dtype, qkv, bias_table, out, dout, lse, dqkv, dbias, c, s);
     if (rc >= 0) return rc;
   }
+  CTU_REQUIRE(c.drop.thr16 == 0, "attention dropout runs on the MFMA kernels only (bf16, or fp32 with <= 224 tokens)");
   const size_t tbl_bytes = dbias ? (size_t)c.relm * c.relm * c.relm * sizeof(float) : 0;
 #define ATT_BWD(T, DH)                                                                                               \
   do {                                                                                                               \
@@ -424,4 +442,15 @@ extern "C" int ctu_attn_bwd(ctu_dtype dtype, const void* qkv, const float* bias_
   else { CTU_DISPATCH(dtype, ATT_BWD(float, 64), ATT_BWD(bf16, 64)); }
 #undef ATT_BWD
   return ctu_check_launch("attn_bwd");
+}
+
+extern "C" int ctu_attn_bwd(ctu_dtype dtype, const void* qkv, const float* bias_table, const void* out,
+                            const void* dout, const float* lse, void* dqkv, float* dbias, const ctu_attn_geom* g,
+                            ctu_stream_t stream) {
+  return attn_bwd_impl(dtype, qkv, bias_table, out, dout, lse, dqkv, dbias, g, 0.f, 0, 0, stream);
+}
+extern "C" int ctu_attn_bwd_dropout(ctu_dtype dtype, const void* qkv, const float* bias_table, const void* out,
+                                    const void* dout, const float* lse, void* dqkv, float* dbias, const ctu_attn_geom* g,
+                                    float p, uint64_t seed, uint64_t offset, ctu_stream_t stream) {
+  return attn_bwd_impl(dtype, qkv, bias_table, out, dout, lse, dqkv, dbias, g, p, seed, offset, stream);
 }

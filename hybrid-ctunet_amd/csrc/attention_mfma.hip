@@ -79,7 +79,7 @@ __device__ __forceinline__ void load_row_frags(const T* __restrict__ src, int ld
 __device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
 // ------------------------------------------------------------------------------------------------------------
-template <typename T, int DH, int KT>
+template <typename T, int DH, int KT, bool DROP>
 __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_table,
                                                             T* __restrict__ out, float* __restrict__ lse, const AttnCtx c) {
   constexpr int EV = 16 / sizeof(T);
@@ -157,6 +157,17 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const T* __restrict_
       lsum += __shfl_xor(lsum, 32, 64);
       l = l * alpha + lsum;
       m = mnew;
+      if (DROP) {  // the normaliser keeps every probability; dropped ones leave the P V product (1/(1-p) joins 1/l below)
+#pragma unroll
+        for (int t = 0; t < CH; ++t)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const uint32_t keep = attn_keep4(c.drop, blockIdx.x, q, (kc + t) * 8 + 2 * g4 + h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (!((keep >> j) & 1u)) s[t][4 * g4 + j] = 0.f;
+          }
+      }
 #pragma unroll
       for (int dt = 0; dt < DH / 32; ++dt)
 #pragma unroll
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const T* __restrict_
       }
     }
     if (qok) {
-      const float inv = 1.0f / l;
+      const float inv = (DROP ? c.drop.scale : 1.0f) / l;
       T* orow = out + attn_row(c, grp, q) * c.dim + head * DH;
 #pragma unroll
       for (int dt = 0; dt < DH / 32; ++dt)
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const T* __restrict_
 
 // ------------------------------------------------------------------------------------------------------------
 // backward, query side: dQ (and the relative-position-bias gradient).  LDS: K, V.
-template <typename T, int DH, int KT>
+template <typename T, int DH, int KT, bool DROP>
 __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_table,
                                                               const T* __restrict__ out, const T* __restrict__ dout,
                                                               const float* __restrict__ lse, T* __restrict__ dqkv,
@@ -262,6 +273,14 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(const T* __restric
         Mma<T>::mma(Mma<T>::load(&Ks[(kt * 32 + r) * LD + ks * 16 + 8 * h]), fq[ks], s);
         Mma<T>::mma(Mma<T>::load(&Vs[(kt * 32 + r) * LD + ks * 16 + 8 * h]), fg[ks], dp);
       }
+      if (DROP) {  // dP = keep ? dP_dropped / (1 - p) : 0
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const uint32_t keep = attn_keep4(c.drop, blockIdx.x, q, kt * 8 + 2 * g4 + h);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dp[4 * g4 + j] = ((keep >> j) & 1u) ? dp[4 * g4 + j] * c.drop.scale : 0.f;
+        }
+      }
       float ds[16];
       int bis[16];
 #pragma unroll
@@ -316,7 +335,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(const T* __restric
 }
 
 // backward, key/value side: dK, dV.  LDS: Q, dO, lse, delta.
-template <typename T, int DH, int KT>
+template <typename T, int DH, int KT, bool DROP>
 __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_table,
                                                                const T* __restrict__ out, const T* __restrict__ dout,
                                                                const float* __restrict__ lse, T* __restrict__ dqkv,
@@ -397,6 +416,23 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(const T* __restri
         pv[e] = p;
         ds[e] = p * (dp[e] - Dl[qi]);
       }
+      if (DROP) {  // dV takes the dropped, rescaled probabilities; dS the rescaled gradient of the kept ones
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int q0 = qt * 32 + 8 * g4 + 4 * h + 2 * half;  // even: queries q0, q0 + 1 share one Philox call
+            const uint32_t keep = attn_keep_qpair(c.drop, blockIdx.x, q0 >> 1, key);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int e = 4 * g4 + 2 * half + j;
+              const bool k1 = (keep >> j) & 1u;
+              const float p = pv[e];
+              ds[e] = p * ((k1 ? dp[e] * c.drop.scale : 0.f) - Dl[q0 + j]);
+              pv[e] = k1 ? p * c.drop.scale : 0.f;
+            }
+          }
+      }
 #pragma unroll
       for (int sh = 0; sh < 2; ++sh) {
         float a[8], b[8];
@@ -443,18 +479,29 @@ static dim3 attn_grid(const AttnCtx& c) {
 
 template <typename T, int DH, int KT>
 static int launch_fwd(const void* qkv, const float* bias, void* out, float* lse, const AttnCtx& c, hipStream_t s) {
-  hipLaunchKernelGGL((attn_mfma_fwd_kernel<T, DH, KT>), attn_grid(c), dim3(256), 0, s, (const T*)qkv, bias,
-                     (T*)out, lse, c);
+  if (c.drop.thr16)
+    hipLaunchKernelGGL((attn_mfma_fwd_kernel<T, DH, KT, true>), attn_grid(c), dim3(256), 0, s, (const T*)qkv, bias,
+                       (T*)out, lse, c);
+  else
+    hipLaunchKernelGGL((attn_mfma_fwd_kernel<T, DH, KT, false>), attn_grid(c), dim3(256), 0, s, (const T*)qkv, bias,
+                       (T*)out, lse, c);
   return ctu_check_launch("attn_mfma_fwd");
 }
 template <typename T, int DH, int KT>
 static int launch_bwd(const void* qkv, const float* bias, const void* out, const void* dout, const float* lse, void* dqkv,
                       float* dbias, const AttnCtx& c, hipStream_t s) {
   const dim3 grid = attn_grid(c);
-  hipLaunchKernelGGL((attn_mfma_bwd_q_kernel<T, DH, KT>), grid, dim3(256), 0, s, (const T*)qkv, bias, (const T*)out,
-                     (const T*)dout, lse, (T*)dqkv, dbias, c);
-  hipLaunchKernelGGL((attn_mfma_bwd_kv_kernel<T, DH, KT>), grid, dim3(256), 0, s, (const T*)qkv, bias, (const T*)out,
-                     (const T*)dout, lse, (T*)dqkv, c);
+  if (c.drop.thr16) {
+    hipLaunchKernelGGL((attn_mfma_bwd_q_kernel<T, DH, KT, true>), grid, dim3(256), 0, s, (const T*)qkv, bias, (const T*)out,
+                       (const T*)dout, lse, (T*)dqkv, dbias, c);
+    hipLaunchKernelGGL((attn_mfma_bwd_kv_kernel<T, DH, KT, true>), grid, dim3(256), 0, s, (const T*)qkv, bias, (const T*)out,
+                       (const T*)dout, lse, (T*)dqkv, c);
+  } else {
+    hipLaunchKernelGGL((attn_mfma_bwd_q_kernel<T, DH, KT, false>), grid, dim3(256), 0, s, (const T*)qkv, bias, (const T*)out,
+                       (const T*)dout, lse, (T*)dqkv, dbias, c);
+    hipLaunchKernelGGL((attn_mfma_bwd_kv_kernel<T, DH, KT, false>), grid, dim3(256), 0, s, (const T*)qkv, bias, (const T*)out,
+                       (const T*)dout, lse, (T*)dqkv, c);
+  }
   return ctu_check_launch("attn_mfma_bwd");
 }
 

@@ -1,11 +1,14 @@
 // Geometry helpers shared by the attention translation units (VALU reference kernels and MFMA kernels).
 #pragma once
 #include "common.h"
+#include "philox.h"
 
 struct AttnCtx {
   ctu_attn_geom g;
   int ntok, nd, nh, nw, groups, relm, reloff, dim, ldq;
+  DropCtx drop;  // dropout of the attention probabilities (thr16 = 0: none)
 };
+int ctu_make_drop_ctx(float p, uint64_t seed, uint64_t offset, DropCtx* d);  // dropout.hip
 
 // row of token i of attention group grp in the natural channels-last row order (see ctu_attn_geom)
 __device__ __forceinline__ int64_t attn_row(const AttnCtx& c, int grp, int i) {

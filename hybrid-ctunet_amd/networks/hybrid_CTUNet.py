@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from .resnet import check_norm, generate_model as resnet, get_conv_layer
-from .vit import ViT, _check_dropout
+from .vit import ViT, _check_dropout, feed_forward
 
 LOGIT_PAD = 16  # logits are computed with N padded to 16 columns (MFMA/vector width); only the first n_cls are exposed
 
@@ -121,7 +121,9 @@ class pixelweight_attention(nn.Module):
 
     def __init__(self, dim, dim_head=32, dropout=0.0):
         super().__init__()
-        _check_dropout(dropout)
+        if _check_dropout(dropout) != 0.0:
+            raise NotImplementedError("pixelweight_attention(dropout > 0): no model of the reference passes a dropout here "
+                                      "(hybrid_CTUNet.py:296-297,370 build it with the default 0.0)")
         if dim_head != 32 or dim % 32 != 0:
             raise NotImplementedError("cross-weight kernel is written for dim_head = 32 (the reference's value)")
         self.dim_head = dim_head
@@ -209,6 +211,7 @@ class MultiAxisAttention(nn.Module):
         self.window_size = window_size
         self.norm = nn.LayerNorm(dim)
         self.to_qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.attend = nn.Sequential(nn.Softmax(dim=-1), nn.Dropout(dropout))  # holder of p; softmax + dropout run fused
         self.to_out = nn.Sequential(nn.Linear(dim, dim, bias=False), nn.Dropout(dropout))
         self.rel_pos_bias = nn.Embedding((2 * window_size - 1) ** 3, self.heads)
         pos = torch.arange(window_size)
@@ -221,7 +224,10 @@ class MultiAxisAttention(nn.Module):
     def forward(self, x, residual=None, part=1):
         h = ops.layer_norm(x, self.norm.weight, self.norm.bias)
         qkv = ops.linear(h, self.to_qkv.weight)
-        o = ops.attention(qkv, self.heads, self.scale, self.rel_pos_bias.weight, part, self.window_size)
+        p = self.to_out[1].p if self.training else 0.0
+        o = ops.attention(qkv, self.heads, self.scale, self.rel_pos_bias.weight, part, self.window_size, dropout_p=p)
+        if p > 0.0:
+            return ops.dropout(ops.linear(o, self.to_out[0].weight, None, None, 0), p, residual=residual)
         return ops.linear(o, self.to_out[0].weight, None, residual, 0)
 
 
@@ -236,10 +242,7 @@ class FeedForward(nn.Module):
                                  nn.Linear(inner_dim, dim), nn.Dropout(dropout))
 
     def forward(self, x, residual=None):
-        n = self.net
-        h = ops.layer_norm(x, n[0].weight, n[0].bias)
-        h = ops.linear(h, n[1].weight, n[1].bias, None, 1)
-        return ops.linear(h, n[4].weight, n[4].bias, residual, 0)
+        return feed_forward(self.net, x, residual, self.training)
 
 
 class UpAttentionBlock(nn.Module):

@@ -18,9 +18,10 @@ def pair(t):
 
 
 def _check_dropout(p):
-    if p != 0.0:
-        raise NotImplementedError("dropout > 0 is not implemented on the MI355X path yet (SURVEY.md section 8f rank 4); "
-                                  "the benchmark and the reference README run with dropout_rate=0.0")
+    """nn.Dropout's own argument check (0 <= p <= 1) narrowed to p < 1 (p = 1 zeroes everything: not a training recipe)."""
+    if not 0.0 <= p < 1.0:
+        raise ValueError(f"dropout probability has to be in [0, 1), got {p}")
+    return float(p)
 
 
 class FeedForward(nn.Module):
@@ -33,10 +34,20 @@ class FeedForward(nn.Module):
                                  nn.Linear(hidden_dim, dim), nn.Dropout(dropout))
 
     def forward(self, x, residual=None):
-        n = self.net
-        h = ops.layer_norm(x, n[0].weight, n[0].bias)
-        h = ops.linear(h, n[1].weight, n[1].bias, None, 1)
-        return ops.linear(h, n[4].weight, n[4].bias, residual, 0)
+        return feed_forward(self.net, x, residual, self.training)
+
+
+def feed_forward(n, x, residual, training):
+    """LayerNorm -> Linear -> GELU -> Dropout -> Linear -> Dropout (+ residual) on the parameter holders of `n`.  The
+    dropout-free case keeps the residual in the second GEMM's epilogue."""
+    p1, p2 = (n[3].p, n[5].p) if training else (0.0, 0.0)
+    h = ops.layer_norm(x, n[0].weight, n[0].bias)
+    h = ops.linear(h, n[1].weight, n[1].bias, None, 1)
+    if p1 > 0.0:
+        h = ops.dropout(h, p1)
+    if p2 > 0.0:
+        return ops.dropout(ops.linear(h, n[4].weight, n[4].bias, None, 0), p2, residual=residual)
+    return ops.linear(h, n[4].weight, n[4].bias, residual, 0)
 
 
 class Attention(nn.Module):
@@ -55,12 +66,16 @@ class Attention(nn.Module):
         self.scale = dim_head ** -0.5
         self.norm = nn.LayerNorm(dim)
         self.to_qkv = nn.Linear(dim, inner_dim * 3, bias=False)
+        self.dropout = nn.Dropout(dropout)
         self.to_out = nn.Sequential(nn.Linear(inner_dim, dim), nn.Dropout(dropout))
 
     def forward(self, x, residual=None):
+        p = self.dropout.p if self.training else 0.0
         h = ops.layer_norm(x, self.norm.weight, self.norm.bias)
         qkv = ops.linear(h, self.to_qkv.weight)
-        o = ops.attention(qkv, self.heads, self.scale)
+        o = ops.attention(qkv, self.heads, self.scale, dropout_p=p)
+        if p > 0.0:
+            return ops.dropout(ops.linear(o, self.to_out[0].weight, self.to_out[0].bias, None, 0), p, residual=residual)
         return ops.linear(o, self.to_out[0].weight, self.to_out[0].bias, residual, 0)
 
 
@@ -111,6 +126,7 @@ class ViT(nn.Module):
         x = ops.linear(x, e[2].weight, e[2].bias)
         x = ops.layer_norm(x, e[3].weight, e[3].bias)
         x = ops.add_bcast(x, self.pos_embedding)
+        x = ops.dropout(x, self.dropout.p, self.training)
         for blk in self.transformer:
             x = blk(x)
         return x

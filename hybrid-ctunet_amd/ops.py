@@ -822,12 +822,77 @@ def add_bcast(x, pos):
 # ---------------------------------------------------------------------------------------------------------------
 # attention / fusion / layout
 # ---------------------------------------------------------------------------------------------------------------
-class AttentionFn(torch.autograd.Function):
-    """softmax(scale * q k^T + rel_pos_bias) v on a fused qkv matrix (vit.py:66-78; hybrid_CTUNet.py:481-511).
-    qkv: [B, D, H, W, 3*heads*dh] (part 1/2: window partitions of the volume) or [B, n, 3*heads*dh] (part 0)."""
+# ---------------------------------------------------------------------------------------------------------------
+# dropout.  Masks come from a counter RNG (csrc/philox.h): a dropout call is identified by
+# (seed, offset); backward replays the same pair, nothing is stored.  The state below hands out offsets in call order.
+# ---------------------------------------------------------------------------------------------------------------
+_drop_seed = None
+_drop_offset = 0
+
+
+def manual_seed(seed: int, offset: int = 0):
+    """Seed of the dropout masks (default: torch.initial_seed() at the first dropout call) and the offset of the next
+    dropout call."""
+    global _drop_seed, _drop_offset
+    _drop_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    _drop_offset = int(offset)
+
+
+def dropout_state() -> Tuple[int, int]:
+    """(seed, offset of the next dropout call)."""
+    global _drop_seed
+    if _drop_seed is None:
+        _drop_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+    return _drop_seed, _drop_offset
+
+
+def _next_drop_key() -> Tuple[int, int]:
+    global _drop_offset
+    seed, off = dropout_state()
+    _drop_offset = off + 1
+    return seed, off
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout(p) in training mode, optionally followed by `+ residual` (the reference's `x = attn(x) + x`)."""
 
     @staticmethod
-    def forward(ctx, qkv, bias_table, part: int, win: int, heads: int, scale: float):
+    def forward(ctx, x, residual, p: float):
+        _check_act(x)
+        x = x.contiguous()
+        if residual is not None:
+            residual = residual.contiguous()
+            assert residual.shape == x.shape and residual.dtype == x.dtype
+        ctx.key = (float(p),) + _next_drop_key()
+        ctx.has_res = residual is not None
+        y = torch.empty_like(x)
+        call("ctu_dropout", dcode(x.dtype), ptr(x), ptr(residual), ptr(y), x.numel(), *ctx.key, stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        gx = torch.empty_like(gy)
+        call("ctu_dropout", dcode(gy.dtype), ptr(gy), None, ptr(gx), gy.numel(), *ctx.key, stream())
+        return gx, (gy if ctx.has_res else None), None
+
+
+def dropout(x, p: float, training: bool = True, residual=None):
+    """y = dropout(x) [+ residual]; identity [+ residual] when p == 0 or not training (nn.Dropout semantics)."""
+    if p < 0.0 or p >= 1.0:
+        raise ValueError(f"dropout probability has to be in [0, 1), got {p}")
+    if p == 0.0 or not training:
+        return x if residual is None else x + residual
+    return DropoutFn.apply(x, residual, p)
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(scale * q k^T + rel_pos_bias) v on a fused qkv matrix (vit.py:66-78; hybrid_CTUNet.py:481-511).
+    qkv: [B, D, H, W, 3*heads*dh] (part 1/2: window partitions of the volume) or [B, n, 3*heads*dh] (part 0).
+    drop_p > 0: dropout of the softmax probabilities (vit.py:74, hybrid_CTUNet.py:459-462), mask regenerated in backward."""
+
+    @staticmethod
+    def forward(ctx, qkv, bias_table, part: int, win: int, heads: int, scale: float, drop_p: float = 0.0):
         _check_act(qkv)
         dim = qkv.shape[-1] // 3
         dh = dim // heads
@@ -841,7 +906,13 @@ class AttentionFn(torch.autograd.Function):
             groups, ntok = B * (D // win) * (H // win) * (W // win), win ** 3
         out = torch.empty((*qkv.shape[:-1], dim), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((groups * heads, ntok), dtype=torch.float32, device=qkv.device)
-        call("ctu_attn_fwd", dcode(qkv.dtype), ptr(qkv), ptr(bias_table), ptr(out), ptr(lse), geo, stream())
+        ctx.drop = None
+        if drop_p > 0.0:
+            ctx.drop = (float(drop_p),) + _next_drop_key()
+            call("ctu_attn_fwd_dropout", dcode(qkv.dtype), ptr(qkv), ptr(bias_table), ptr(out), ptr(lse), geo, *ctx.drop,
+                 stream())
+        else:
+            call("ctu_attn_fwd", dcode(qkv.dtype), ptr(qkv), ptr(bias_table), ptr(out), ptr(lse), geo, stream())
         ctx.save_for_backward(qkv, bias_table, out, lse)
         ctx.geo = geo
         return out
@@ -852,13 +923,25 @@ class AttentionFn(torch.autograd.Function):
         gout = gout.contiguous()
         gqkv = torch.empty_like(qkv)
         gbias = torch.zeros_like(bias_table) if bias_table is not None else None
-        call("ctu_attn_bwd", dcode(qkv.dtype), ptr(qkv), ptr(bias_table), ptr(out), ptr(gout), ptr(lse), ptr(gqkv),
-             ptr(gbias), ctx.geo, stream())
-        return gqkv, gbias, None, None, None, None
+        if ctx.drop is not None:
+            call("ctu_attn_bwd_dropout", dcode(qkv.dtype), ptr(qkv), ptr(bias_table), ptr(out), ptr(gout), ptr(lse),
+                 ptr(gqkv), ptr(gbias), ctx.geo, *ctx.drop, stream())
+        else:
+            call("ctu_attn_bwd", dcode(qkv.dtype), ptr(qkv), ptr(bias_table), ptr(out), ptr(gout), ptr(lse), ptr(gqkv),
+                 ptr(gbias), ctx.geo, stream())
+        return gqkv, gbias, None, None, None, None, None
 
 
-def attention(qkv, heads, scale, bias_table=None, part=0, win=0):
-    return AttentionFn.apply(qkv, bias_table, part, win, heads, scale)
+def attention(qkv, heads, scale, bias_table=None, part=0, win=0, dropout_p: float = 0.0, training: bool = True):
+    return AttentionFn.apply(qkv, bias_table, part, win, heads, scale, dropout_p if training else 0.0)
+
+
+def attention_dropout_mask(pairs: int, ntok: int, p: float, seed: int, offset: int, device) -> torch.Tensor:
+    """Verification hook: the keep flags [pairs = groups*heads, ntok, ntok] (uint8) the attention kernels apply for the
+    dropout call (p, seed, offset)."""
+    keep = torch.empty((pairs, ntok, ntok), dtype=torch.uint8, device=device)
+    call("ctu_attn_dropout_mask", ptr(keep), pairs, ntok, float(p), seed, offset, stream())
+    return keep
 
 
 class PwaFn(torch.autograd.Function):

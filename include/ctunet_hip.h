@@ -283,6 +283,26 @@ int ctu_sw_normalize(float* out, const float* count, int32_t B, int32_t C, int64
 int ctu_hybrid_argmax(const float* p1, const float* p2, int32_t C, int64_t S, int64_t* labels1, int64_t* labels2,
                       int64_t* labels_hybrid, ctu_stream_t stream);
 
+/* Dropout (reference: nn.Dropout at networks/vit.py:38,40,57,63,74 and
+ * networks/hybrid_CTUNet.py:459-467,521-523).  Masks are a pure function of (seed, offset, element index) through
+ * Philox4x32-10 with 16-bit draws (keep iff draw >= round(p * 65536); survivors scaled by 65536 / (65536 - thr)), so the
+ * backward pass calls the same entry point on the gradient with the forward's (p, seed, offset) and nothing is stored.
+ * `offset` identifies the dropout call (low 32 bits used).  y = dropout(x) + residual (residual may be NULL: the
+ * reference's `x = attn(x) + x` with the dropout inside attn).  x, residual, y: n elements of `dtype`, 16-byte aligned;
+ * y may alias x. */
+int ctu_dropout(ctu_dtype dtype, const void* x, const void* residual, void* y, int64_t n, float p, uint64_t seed,
+                uint64_t offset, ctu_stream_t stream);
+/* ctu_attn_fwd / ctu_attn_bwd with dropout of the attention probabilities (after the softmax, before P.v; the reference's
+ * self.dropout(attn) / nn.Sequential(Softmax, Dropout)).  MFMA kernels only: bf16, or fp32 with <= 224 tokens. */
+int ctu_attn_fwd_dropout(ctu_dtype dtype, const void* qkv, const float* bias_table, void* out, float* lse,
+                         const ctu_attn_geom* g, float p, uint64_t seed, uint64_t offset, ctu_stream_t stream);
+int ctu_attn_bwd_dropout(ctu_dtype dtype, const void* qkv, const float* bias_table, const void* out, const void* dout,
+                         const float* lse, void* dqkv, float* dbias, const ctu_attn_geom* g, float p, uint64_t seed,
+                         uint64_t offset, ctu_stream_t stream);
+/* Verification hook: the keep flags the attention kernels apply, keep[pairs = groups*heads][ntok][ntok], one byte each. */
+int ctu_attn_dropout_mask(uint8_t* keep, int32_t pairs, int32_t ntok, float p, uint64_t seed, uint64_t offset,
+                          ctu_stream_t stream);
+
 /* fp32 <-> dtype casts and fills */
 int ctu_cast(const void* src, ctu_dtype src_dtype, void* dst, ctu_dtype dst_dtype, int64_t n, ctu_stream_t stream);
 

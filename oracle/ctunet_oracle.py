@@ -284,6 +284,7 @@ class MultiAxisAttention(nn.Module):
         self.scale = dim_head ** -0.5
         self.norm = nn.LayerNorm(dim)
         self.to_qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.attend = nn.Sequential(nn.Softmax(dim=-1), nn.Identity())  # Identity = nn.Dropout(0) (:459-462)
         self.to_out = nn.Sequential(nn.Linear(dim, dim, bias=False), nn.Identity())
         self.rel_pos_bias = nn.Embedding((2 * window_size - 1) ** 3, self.heads)
         self.register_buffer("rel_pos_indices", rel_pos_indices(window_size), persistent=False)
@@ -297,7 +298,7 @@ class MultiAxisAttention(nn.Module):
         sim = q @ k.transpose(-1, -2)
         bias = self.rel_pos_bias(self.rel_pos_indices)  # (n, n, h)
         sim = sim + bias.permute(2, 0, 1)
-        out = torch.softmax(sim, dim=-1) @ v            # (B', h, n, dh)
+        out = self.attend(sim) @ v                      # (B', h, n, dh)
         out = out.transpose(1, 2).reshape(b * X * Y * Z, w1, w2, w3, d)
         out = self.to_out(out)
         return out.reshape(b, X, Y, Z, w1, w2, w3, d)
@@ -459,6 +460,7 @@ class Attention(nn.Module):
         self.heads = heads
         self.scale = dim_head ** -0.5
         self.norm = nn.LayerNorm(dim)
+        self.dropout = nn.Identity()  # nn.Dropout(0) on the attention probabilities (vit.py:57,74)
         self.to_qkv = nn.Linear(dim, inner * 3, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Identity())
 
@@ -466,7 +468,7 @@ class Attention(nn.Module):
         b, n, _ = x.shape
         x = self.norm(x)
         q, k, v = (t.reshape(b, n, self.heads, -1).transpose(1, 2) for t in self.to_qkv(x).chunk(3, dim=-1))
-        attn = torch.softmax((q @ k.transpose(-1, -2)) * self.scale, dim=-1)
+        attn = self.dropout(torch.softmax((q @ k.transpose(-1, -2)) * self.scale, dim=-1))
         out = (attn @ v).transpose(1, 2).reshape(b, n, -1)
         return self.to_out(out)
 
@@ -500,6 +502,7 @@ class ViT(nn.Module):
         self.to_patch_embedding = nn.Sequential(_Placeholder(), nn.LayerNorm(patch_dim), nn.Linear(patch_dim, dim),
                                                 nn.LayerNorm(dim))
         self.pos_embedding = nn.Parameter(torch.randn(1, num_patches, dim))
+        self.dropout = nn.Identity()  # nn.Dropout(emb_dropout = 0) (vit.py:121)
         self.transformer = nn.ModuleList([TransformerBlock(dim, heads, dim_head, mlp_dim) for _ in range(depth)])
 
     def patchify(self, img):
@@ -513,7 +516,7 @@ class ViT(nn.Module):
         x = self.patchify(img)
         for m in list(self.to_patch_embedding)[1:]:
             x = m(x)
-        x = x + self.pos_embedding
+        x = self.dropout(x + self.pos_embedding)
         for blk in self.transformer:
             x = blk(x)
         return x

@@ -61,9 +61,12 @@ def test_constructor_contract():
                      patch_frame=16)
         with pytest.raises(NotImplementedError):
             H.CUNet(out_channels=14, model_depth=50, norm_name="batch")
-        with pytest.raises(NotImplementedError):
+        with pytest.raises(ValueError):  # torch's nn.Dropout raises ValueError outside [0, 1]
             H.TUNet(in_channels=1, dim_conv_stem=64, out_channels=14, img_size=(96, 96), frames=96, patch_frame=8,
-                    dropout_rate=0.2)
+                    dropout_rate=1.2)
+        t = H.TUNet(in_channels=1, dim_conv_stem=64, out_channels=14, img_size=(96, 96), frames=96, patch_frame=8,
+                    dropout_rate=0.2)   # the authors' dr0.2 recipe (test_CTUNet_final.py:448)
+        assert t.vit.dropout.p == 0.2
         with pytest.raises(AssertionError):  # vit.py:108-109
             H.TUNet(in_channels=1, dim_conv_stem=64, out_channels=14, img_size=(100, 96), frames=96, patch_frame=8)
 

@@ -11,6 +11,12 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+def _rel_l2(a, b):
+    """|a - b|_2 / |b|_2: bf16 run-to-run noise (reordered atomics feed rounding flips) is ~1e-2 here, while the max norm over
+    10^7 logits wanders up to ~5 %; wrong weights / windows / masks give O(1) in either norm."""
+    return ((a.float() - b.float()).norm() / b.float().norm()).item()
+
+
 def _pointwise(outputs, channels_last=False, dtype=torch.float32):
     """A predictor that is the same fp32 arithmetic on host and device: per-voxel functions of the window."""
     def predictor(w):
@@ -138,7 +144,7 @@ def test_hybrid_complement_equals_oracle(C, shape):
         H.hybrid_complement(p1.to(DEV), p2[:, :2].to(DEV))
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 5e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 8e-2)])
 def test_ctunet_through_sliding_window_and_checkpoint(tmp_path, precision, tol):
     """One real model: CTUNet -> save_checkpoint -> fresh CTUNet + load_checkpoint -> the same sliding-window outputs
     (fp32 mode: to rounding of reordered atomics; bf16 mode: to bf16 noise - a model with other weights is off by O(1));
@@ -155,14 +161,19 @@ def test_ctunet_through_sliding_window_and_checkpoint(tmp_path, precision, tol):
     net2 = H.build_model("ctunet", model_depth=50).to(DEV).set_precision(precision).eval()
     with torch.no_grad():
         c1, _ = H.sliding_window_inference(x, (96, 96, 96), 1, net2, overlap=0.5, mode="gaussian")
-    assert (c1 - a1).abs().max() > 0.2 * a1.abs().max()       # other weights: a different function
+    assert _rel_l2(c1, a1) > 0.3                               # other weights: a different function
     assert H.load_checkpoint(net2, f, strict=True) == (5, 0.5)
     with torch.no_grad():
         b1, b2 = H.sliding_window_inference(x, (96, 96, 96), 1, net2, overlap=0.5, mode="gaussian")
     for a, b_ in ((a1, b1), (a2, b2)):
-        assert (a - b_).abs().max() <= tol * a.abs().max()
+        assert _rel_l2(b_, a) <= tol
     l1, l2, lh = H.hybrid_complement(a1[0], a2[0])
-    assert torch.equal(l1, a1[0].argmax(0)) and torch.equal(l2, a2[0].argmax(0))
+    for lab, logit in ((l1, a1[0]), (l2, a2[0])):
+        # the reference takes argmax of the SOFTMAX: logits closer than an fp32 ulp of exp() tie there and the first class
+        # wins, so a label may differ from the logits' argmax only across such a gap
+        diff = lab != logit.argmax(0)
+        top2 = logit.topk(2, 0).values
+        assert ((top2[0] - top2[1])[diff] < 1e-6).all() and diff.float().mean() < 1e-2
     d = H.dice_per_organ(lh, l1, 14)
     assert len(d) == 13 and all(0.0 <= v <= 1.0 for v in d)
 
@@ -179,7 +190,7 @@ def test_single_output_models_through_sliding_window():
         assert out.shape == (1, 14, 96, 100, 96) and torch.isfinite(out).all()
         # rows 0..3 of dim H are covered by the first window only: the blend returns that window's logits unchanged
         # (bf16 run-to-run noise from reordered atomics; a wrong window or weight map would be off by O(1))
-        assert (out[:, :, :, :4] - one[:, :, :, :4]).abs().max() <= 5e-2 * one.abs().max()
+        assert _rel_l2(out[:, :, :, :4], one[:, :, :, :4]) <= 8e-2
 
 
 def test_optimizer_state_round_trip(tmp_path):

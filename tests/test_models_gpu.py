@@ -274,6 +274,6 @@ def test_constructor_errors(H):
                  patch_frame=16)
     with pytest.raises(NotImplementedError):
         H.CUNet(out_channels=14, model_depth=50, norm_name="batch")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
         H.TUNet(in_channels=1, dim_conv_stem=64, out_channels=14, img_size=(96, 96), frames=96, patch_frame=8,
-                dropout_rate=0.2)
+                dropout_rate=1.5)
