@@ -15,6 +15,7 @@ struct GemmNtArgs {
   double* in_acc;  // optional [M / in_rows][N][2] += (sum, sum of squares) of the output columns per batch item
   int in_rows;     // rows per batch item (a multiple of 128: no tile straddles two items)
   int tiles_m, tiles_n, ksteps, ks_per_split, nwork;  // filled by the launcher
+  int debug;       // measurement hook (ctu_set_option "nt_debug"): 1 = no output stores, 2 = no operand DMA
 };
 
 // returns 0 on launch, -1 if the shape is out of range (caller falls back to the generic kernel)

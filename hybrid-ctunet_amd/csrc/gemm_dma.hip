@@ -19,6 +19,8 @@
 #include "dma.h"
 #include "gemm_dma.h"
 
+#include <stdlib.h>
+
 namespace {
 
 struct WorkItem {
@@ -50,6 +52,18 @@ __device__ __forceinline__ size_t epilogue_offset(const ctu_epilogue& ep, bf16* 
 }
 
 }  // namespace
+
+// wait for the oldest of `a + 1` stages in flight (a in [0, MAXA], steady state a = MAXA): a compile-time vmcnt each
+// EXTRA: vector-memory operations issued AFTER those stages that may stay in flight as well (vmcnt retires loads, LDS-DMA
+// and stores together, in issue order: the epilogue stores of the previous tile are younger than the stage waited for)
+template <int IPW, int MAXA, int EXTRA = 0> __device__ __forceinline__ void wait_stage(int a) {
+  if constexpr (MAXA <= 0) {
+    wait_vm_then_barrier<EXTRA>();
+  } else {
+    if (a >= MAXA) wait_vm_then_barrier<MAXA * IPW + EXTRA>();
+    else wait_stage<IPW, MAXA - 1, EXTRA>(a);
+  }
+}
 
 // R = ring depth (stages of 64 k): R - 1 stages are in flight while one is computed.  A step of a small tile is a
 // handful of MFMAs, far less than one DMA latency, so small tiles (and launches with at most one workgroup per CU)
@@ -86,15 +100,20 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
   // source-side bank swizzle of a tile row's 16-B slots (conflict-free ds_read_b128 of 32-row fragments)
   auto swz = [](int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; };
 
-  auto decode = [&](int wi) {
+  // Work items = (m tile, n tile, k split), n fastest.  The grid is a multiple of cols = tiles_n * splitk (launcher), so a
+  // persistent workgroup keeps its (n tile, k split) for life and only walks down the m tiles: no division per item (the
+  // scalar div / mod sequences of a per-item decode were a tenth of a short-K tile's instruction stream).
+  const int cols = p.tiles_n * p.splitk;
+  const int my_col = vid % cols, tm_first = vid / cols, tm_step = (int)gridDim.x / cols;
+  const int my_n0 = (my_col % p.tiles_n) * BN;
+  const int my_kb = (my_col / p.tiles_n) * p.ks_per_split;
+  const int my_ke = min(p.ksteps, my_kb + p.ks_per_split);
+  auto item_at = [&](int tm) {
     WorkItem it;
-    const int tn = wi % p.tiles_n;
-    const int q = wi / p.tiles_n;
-    const int sp = q % p.splitk, tm = q / p.splitk;
     it.m0 = tm * BM;
-    it.n0 = tn * BN;
-    it.kb = sp * p.ks_per_split;
-    it.ke = min(p.ksteps, it.kb + p.ks_per_split);
+    it.n0 = my_n0;
+    it.kb = my_kb;
+    it.ke = my_ke;
     return it;
   };
 
@@ -119,6 +138,7 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
   }
 
   auto issue = [&](const WorkItem& it, int ks, int st) {
+    if (p.debug & 2) return;
     const int k0 = ks * BK;
     const bool first = k0 < p.C1;
     const bf16* a = first ? p.a1 : p.a2;
@@ -168,7 +188,7 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
 
   bf16* out = reinterpret_cast<bf16*>(p.out);
 
-  if (vid >= p.nwork) return;
+  if (tm_first >= p.tiles_m) return;
   // running InstanceNorm sums of this workgroup (in_acc): lane (r, h) owns column r of each of its n tiles
   float rs1[NJ], rs2[NJ];
 #pragma unroll
@@ -203,25 +223,31 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // red may be rewritten by the next flush
   };
   // two cursors over the flat sequence of (work item, k step) stages of this workgroup: issue runs R - 1 ahead of compute
-  int wi = vid, iwi = vid;
-  WorkItem cur = decode(wi), icur = cur;
+  int tm = tm_first, itm = tm_first;
+  WorkItem cur = item_at(tm), icur = cur;
   int ks = cur.kb, iks = cur.kb;
   bool idone = false;
   auto issue_next = [&](int slot) {
     issue(icur, iks, slot);
     if (++iks == icur.ke) {
-      iwi += gridDim.x;
-      if (iwi < p.nwork) { icur = decode(iwi); iks = icur.kb; }
+      itm += tm_step;
+      if (itm < p.tiles_m) { icur.m0 = itm * BM; iks = icur.kb; }
       else idone = true;
     }
   };
   int ahead = 0, st = 0, ist = 0;  // stages issued but not yet computed; compute slot; next issue slot
+  bool after_epi = false;
+  constexpr int EPI_STORES = (BM / 64) * (32 / (512 / (BN / 2)));  // MI * NR store instructions per wave and whole tile
 #pragma unroll 1
   for (int q = 0; q < R - 1 && !idone; ++q) { issue_next(ist); ist = ist + 1 == R ? 0 : ist + 1; ++ahead; }
   while (true) {
     // stage st has landed in every wave (the ahead - 1 younger ones may still be in flight), and every wave is done
     // reading the slot computed in the previous iteration - the one refilled next
-    wait_vm_then_barrier_n((ahead - 1) * IPW);
+    // right after a whole tile's epilogue its stores need not drain: the stage needed now was issued before them
+    // (a write-heavy short-K GEMM otherwise alternates between "stores acknowledged" and "next stage landed")
+    if (after_epi) wait_stage<IPW, R - 2, EPI_STORES>(ahead - 1);
+    else wait_stage<IPW, R - 2>(ahead - 1);
+    after_epi = false;
     if (!idone) { issue_next(ist); ist = ist + 1 == R ? 0 : ist + 1; ++ahead; }
     const bool last = ks + 1 == cur.ke;
     --ahead;
@@ -341,7 +367,7 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
               }
               bf16* dst;
               const size_t off = epilogue_offset(p.ep, out, m, n, dst);
-              store8(dst + off, x);
+              if (!(p.debug & 1)) store8(dst + off, x);
             }
           }
           __builtin_amdgcn_wave_barrier();
@@ -352,9 +378,12 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-      wi += gridDim.x;
-      if (wi >= p.nwork) break;
-      cur = decode(wi);
+      // (whole tiles only: a tail tile may skip a store, and counting one that was never issued would end the wait early;
+      //  pre_out doubles the stores - counting fewer than issued only waits longer)
+      after_epi = p.splitk <= 1 && cur.m0 + BM <= p.M && cur.n0 + BN <= p.N;
+      tm += tm_step;
+      if (tm >= p.tiles_m) break;
+      cur.m0 = tm * BM;
       ks = cur.kb;
     } else {
       ++ks;
@@ -364,7 +393,279 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
   if (stat_live) stat_flush();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// gemm_nt_stream : the short-K, long-M layers (1x1x1 convs of the ResNet bottlenecks and their data gradients:
+// M = 10^5..10^6 rows, K = 32 / 64 / 128, N a multiple of 128) - pure streams of A in and out out, where the general
+// kernel above spends ~10 k cycles per 128 x 128 tile on its own instruction stream and LDS round trips (measured with
+// neither loads nor stores issued) against ~1 k cycles of MFMA.  Here:
+//   * a workgroup keeps ONE 128-column tile of W for life, as MFMA fragments in registers (K / 16 x 2 per wave), and walks
+//     down the m tiles: a stage is a whole 128 x K tile of A (one barrier and one DMA group per tile, no W traffic);
+//   * the product is taken transposed (W fragment as the MFMA A operand): lane (r, h) owns output ROW r of a 32-row tile
+//     and, in registers 4 g + c, columns 8 g + 4 h + c.  One v_permlane32_swap per register pair trades the upper lane
+//     half of group 2 q against the lower half of group 2 q + 1, leaving 8 consecutive columns (16 q + 8 h ..) per lane:
+//     16-byte bf16 stores straight from registers - no LDS patch, no write -> read round trips in the epilogue;
+//   * the epilogue stores of tile t stay in flight across the wait for tile t + 1 (vmcnt retires in issue order and the
+//     stage needed was issued before them);
+//   * InstanceNorm sums (in_acc): per-lane partial column sums in registers across all tiles of a batch item, reduced over
+//     the 32 row lanes once per flush.
+// KS = K / 16.  Requires M % 128 == 0, N % 128 == 0, one source, plain epilogue (optional residual), no split K.
+// ---------------------------------------------------------------------------------------------------------
+// all-reduce (sum) inside each 16-lane DPP row: row_ror 8, 4, 2, 1
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+  return v;
+}
+
+template <int KS, bool STATS>
+__global__ __launch_bounds__(256, 2) void gemm_nt_stream_kernel(const GemmNtArgs p) {
+  constexpr int K = KS * 16;
+  constexpr int ROWB = K * 2;               // bytes of an A row
+  constexpr int SPR = K / 8;                // 16-B slots per row
+  constexpr int RPI = 1024 / ROWB;          // rows per DMA wave-instruction
+  constexpr int STAGE = 128 * ROWB;
+  constexpr int R = STAGE >= 32768 ? 2 : 4; // ring depth: 64 KiB (K = 128, 64), 32 KiB (K = 32)
+  constexpr int APW = 128 / RPI / 4;        // DMA instructions per wave and stage: 8 / 4 / 2
+  constexpr int GRP = APW >= 4 ? 4 : APW;   // ... issued in groups of
+  constexpr int RBR = 256 / ROWB;           // rows per 256-B bank row
+  constexpr int STORES = 8;                 // store instructions per wave and tile (2 x 2 x 2 vectors)
+  constexpr int OUT_BYTES = 4 * 32 * 128;   // per wave 32 rows x 64 bf16 columns: the store staging (and the stat_flush scratch)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[R * STAGE + OUT_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int vid = xcd_remap(blockIdx.x, gridDim.x);
+  const int cols = p.N >> 7;
+  const int n0 = (vid % cols) * 128;
+  // a workgroup takes a CONTIGUOUS range of m tiles (consecutive rows stream from consecutive DRAM pages, and a range
+  // rarely straddles two batch items: one stat_flush per workgroup); the `cols` workgroups of an index share their A
+  // tiles through the XCD's L2 (consecutive vid)
+  const int per_col = (int)gridDim.x / cols;
+  const int chunk = ((p.M >> 7) + per_col - 1) / per_col;
+  int tm = (vid / cols) * chunk;
+  const int tiles_m = min(p.M >> 7, tm + chunk);
+  constexpr int tm_step = 1;
+  if (tm >= tiles_m) return;
+  auto swz = [](int row) { return (row / RBR) & (SPR - 1); };
+
+  // ---- this wave's W fragments: columns n0 + 64 wn + 32 j + r, k = 16 kk + 8 h .. + 7 ----
+  bf16x8 wf[2][KS];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      if (p.w_kn) {  // W[k][n] (data gradient reads the forward weight as stored)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wf[j][kk][e] = p.w[(size_t)(kk * 16 + 8 * h + e) * p.N + n];
+      } else {
+        wf[j][kk] = *reinterpret_cast<const bf16x8*>(p.w + (size_t)n * K + kk * 16 + 8 * h);
+      }
+    }
+  }
+
+  // ---- DMA: per-lane source offsets inside a tile (constant for the kernel), lane-linear LDS image ----
+  unsigned va[APW];
+#pragma unroll
+  for (int j = 0; j < APW; ++j) {
+    const int row = RPI * (APW * wave + j) + lane / SPR;
+    va[j] = (unsigned)(row * ROWB + (((lane % SPR) ^ swz(row)) << 4));
+  }
+  auto issue = [&](int t, int slot) {
+    const bf16* base = p.a1 + (size_t)t * 128 * K;
+    unsigned char* dst = smem + slot * STAGE + APW * wave * 1024;
+#pragma unroll
+    for (int g = 0; g < APW / GRP; ++g) {
+      unsigned v[GRP];
+#pragma unroll
+      for (int j = 0; j < GRP; ++j) v[j] = va[g * GRP + j];
+      dma16_groupN<GRP, 1024>(base, v, dst + g * GRP * 1024);
+    }
+  };
+  int aoff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wm * 64 + i * 32 + r;
+    aoff[i] = row * ROWB + ((h ^ swz(row)) << 4);  // k step kk: ^ (kk << 5)
+  }
+
+  f32x16 acc[2][2];
+  float rs1[STATS ? 2 : 1][16], rs2[STATS ? 2 : 1][16];
+  if (STATS) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { rs1[j][e] = 0.f; rs2[j][e] = 0.f; }
+  }
+  int stat_b = -1;
+  auto stat_flush = [&]() {
+    if constexpr (STATS) {
+      float* red = reinterpret_cast<float*>(smem + R * STAGE);  // [4 waves][64 columns][2] (the idle store staging)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          // this lane's rows of column (e & 3) + 8 (e >> 2) + 4 h: sum the 32 row lanes - rotations inside the 16-lane
+          // DPP rows (VALU, no LDS crossbar), then one exchange between the two rows of the half
+          float s1 = row16_sum(rs1[j][e]), s2 = row16_sum(rs2[j][e]);
+          s1 += __shfl_xor(s1, 16, 64);
+          s2 += __shfl_xor(s2, 16, 64);
+          if (r == 0) {
+            const int col = j * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            red[(wave * 64 + col) * 2] = s1;
+            red[(wave * 64 + col) * 2 + 1] = s2;
+          }
+          rs1[j][e] = 0.f; rs2[j][e] = 0.f;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (vmcnt untouched: the ring stays in flight)
+      if (tid < 128) {
+        const int wq = tid >> 6, col = tid & 63;  // waves wq (wm = 0) and wq + 2 (wm = 1) hold these columns
+        const float t1 = red[(wq * 64 + col) * 2] + red[((wq + 2) * 64 + col) * 2];
+        const float t2 = red[(wq * 64 + col) * 2 + 1] + red[((wq + 2) * 64 + col) * 2 + 1];
+        atomicAdd(&p.in_acc[((size_t)stat_b * p.N + n0 + tid) * 2], (double)t1);
+        atomicAdd(&p.in_acc[((size_t)stat_b * p.N + n0 + tid) * 2 + 1], (double)t2);
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // red may be rewritten by the next flush
+    }
+  };
+
+  bf16* out = reinterpret_cast<bf16*>(p.out);
+  // (the InstanceNorm-sum variant never carries a residual - stream_ok - and has no registers to spare for one)
+  const bf16* res = STATS ? nullptr : reinterpret_cast<const bf16*>(p.ep.residual);
+  const size_t ldc = (size_t)p.ep.ldc;
+  const size_t lane_off = (size_t)(wm * 64 + r) * ldc + n0 + wn * 64 + 8 * h;  // + (128 tm + 32 i) ldc + 32 j + 16 q
+
+  // ---- ring: tile t of this workgroup lives in slot (count % R); R - 1 tiles in flight ahead of the one computed ----
+  int itm = tm, ahead = 0, slot = 0, islot = 0;
+#pragma unroll 1
+  for (int q = 0; q < R - 1 && itm < tiles_m; ++q) { issue(itm, islot); itm += tm_step; islot = islot + 1 == R ? 0 : islot + 1; ++ahead; }
+  bool after_store = false;
+#pragma unroll 1
+  for (; tm < tiles_m; tm += tm_step) {
+    if (after_store) wait_stage<APW, R - 2, STORES>(ahead - 1);
+    else wait_stage<APW, R - 2>(ahead - 1);
+    if (itm < tiles_m) { issue(itm, islot); itm += tm_step; islot = islot + 1 == R ? 0 : islot + 1; ++ahead; }
+    --ahead;
+
+    const unsigned char* sa = smem + slot * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      bf16x8 fa[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + (aoff[i] ^ (kk << 5)));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][kk], fa[i], acc[i][j], 0, 0, 0);
+    }
+
+    if constexpr (STATS) {
+      const int sb = (tm * 128) / p.in_rows;
+      if (sb != stat_b) {
+        if (stat_b >= 0) stat_flush();
+        stat_b = sb;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) { const float v = acc[i][j][e]; rs1[j][e] += v; rs2[j][e] += v * v; }
+    }
+
+    // rows of this lane in the register layout (residual reads) and in the store layout (8 lanes per 128-B row segment)
+    const size_t tile_off = (size_t)tm * 128 * ldc + lane_off;
+    bf16x8 resv[2][2][2];
+    if (res) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            resv[i][j][q] = *reinterpret_cast<const bf16x8*>(res + tile_off + (size_t)(32 * i) * ldc + 32 * j + 16 * q);
+    }
+    unsigned char* stg = smem + R * STAGE + wave * (32 * 128);
+    const size_t st_off = (size_t)(tm * 128 + wm * 64 + (lane >> 3)) * ldc + n0 + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float x[8];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * q + c]),
+                                                              __float_as_uint(acc[i][j][8 * q + 4 + c]), false, false);
+            x[c] = __uint_as_float(sw[0]);
+            x[4 + c] = __uint_as_float(sw[1]);
+          }
+          if (res) {
+            const bf16x8 rv = resv[i][j][q];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += (float)rv[e];
+          }
+          // row r, 16-B slot 4 j + 2 q + h of the 128-B row, slot ^ (row & 7): conflict-free for the 8-lane write groups
+          // (8 rows, one slot) and for the 16-lane read groups below (2 rows x 8 slots)
+          store8(reinterpret_cast<bf16*>(stg + r * 128 + (((4 * j + 2 * q + h) ^ (r & 7)) << 4)), x);
+        }
+      __builtin_amdgcn_wave_barrier();
+      bf16x8 ov[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = 8 * t + (lane >> 3);
+        ov[t] = *reinterpret_cast<const bf16x8*>(stg + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (!(p.debug & 1)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)  // each store: 8 whole 128-B row segments
+          *reinterpret_cast<bf16x8*>(out + st_off + (size_t)(32 * i + 8 * t) * ldc) = ov[t];
+      }
+    }
+    after_store = !(p.debug & 1);
+    slot = slot + 1 == R ? 0 : slot + 1;
+  }
+  if (STATS && stat_b >= 0) stat_flush();
+}
+
+static bool stream_ok(const GemmNtArgs& p) {
+  const ctu_epilogue& e = p.ep;
+  return (p.K == 32 || p.K == 64 || p.K == 128) && p.a2 == nullptr && p.C1 == p.K && p.N % 128 == 0 && p.M % 128 == 0 &&
+         p.M >= 128 * 1024 && p.splitk <= 1 && !e.bias && e.act == 0 && !e.pre_out && !e.scatter && e.n_split <= 0 &&
+         (!p.in_acc || (p.in_rows % 128 == 0 && !e.residual)) && !getenv("CTU_NT_NO_STREAM");
+}
+static void launch_stream(const GemmNtArgs& p, hipStream_t stream) {
+  const int cols = p.N / 128;
+  const int grid = cols >= 512 ? cols : 512 / cols * cols;
+  const dim3 g(grid), b(256);
+#define CTU_STREAM(KS)                                                                                   \
+  do {                                                                                                   \
+    if (p.in_acc) hipLaunchKernelGGL((gemm_nt_stream_kernel<KS, true>), g, b, 0, stream, p);             \
+    else hipLaunchKernelGGL((gemm_nt_stream_kernel<KS, false>), g, b, 0, stream, p);                     \
+  } while (0)
+  if (p.K == 128) CTU_STREAM(8);
+  else if (p.K == 64) CTU_STREAM(4);
+  else CTU_STREAM(2);
+#undef CTU_STREAM
+}
+
+int ctu_option_nt_debug();
 int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {
+  p.debug = ctu_option_nt_debug();
+  if (stream_ok(p)) { launch_stream(p, stream); return 0; }
   // tile choice: the largest tile that still yields ~200 work items for the 512 resident workgroups; the 864-token
   // ViT trunk (M = 864) gets 64 x 64 tiles rather than a split K with its atomics and second pass
   const auto items = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
@@ -385,7 +686,10 @@ int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {
   if (nwork >= (1ll << 31)) return -1;
   p.nwork = (int)nwork;
   const bool one_per_cu = p.nwork <= 256;  // a single workgroup per CU may take the whole LDS for a deeper ring
-  const int grid = p.nwork < 512 ? p.nwork : 512;  // else two resident workgroups per CU, persistent over the work items
+  // two resident workgroups per CU, persistent over the work items; a multiple of the (n tile, k split) columns so that a
+  // workgroup keeps its column (see the kernel)
+  const int cols = p.tiles_n * p.splitk;
+  const int grid = p.nwork < 512 ? p.nwork : (cols >= 512 ? cols : 512 / cols * cols);
   const dim3 g(grid), b(256);
   if (bk32) {
     if (p.w_kn) return -1;

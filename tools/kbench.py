@@ -50,6 +50,29 @@ def nt(M, N, K):
     report(f"igemm_nt M={M} N={N} K={K}", us, 2.0 * M * N * K, 2.0 * (M * (N + K) + N * K))
 
 
+def nt_model(M, N, K, variant, sets=4, B=2):
+    """The in-model variants on rotating operand sets (4 x > 256 MB: nothing comes from the Infinity Cache):
+    plain | stats (InstanceNorm sums in the epilogue) | dgrad (reduction-major W + residual)."""
+    xs = [torch.randn(M, K, device=dev, dtype=DT) for _ in range(sets)]
+    outs = [torch.empty(M, N, device=dev, dtype=DT) for _ in range(sets)]
+    res = [torch.randn(M, N, device=dev, dtype=DT) for _ in range(sets)] if variant == "dgrad" else None
+    w = torch.randn(N, K, device=dev, dtype=DT) if variant != "dgrad" else torch.randn(K, N, device=dev, dtype=DT)
+    acc = torch.zeros(B * N * 2, device=dev, dtype=torch.float64)
+    it = [0]
+
+    def run():
+        i = it[0] = (it[0] + 1) % sets
+        if variant == "plain":
+            ops._plain_gemm(xs[i], w, outs[i], M, K, N)
+        elif variant == "stats":
+            ops._plain_gemm(xs[i], w, outs[i], M, K, N, in_acc=acc, in_rows=M // B)
+        else:
+            ops._plain_gemm(xs[i], w, outs[i], M, K, N, w_kn=1, residual=res[i])
+    us = timeit(run, reps=24)
+    extra = 2.0 * M * N if variant == "dgrad" else 0.0
+    report(f"igemm_nt[{variant}] M={M} N={N} K={K}", us, 2.0 * M * N * K, 2.0 * (M * (N + K) + N * K) + extra)
+
+
 def halo(B, D, H, W, C, N, what):
     x = torch.randn(B, D, H, W, C, device=dev, dtype=DT)
     w = torch.nn.Parameter(torch.randn(N, C, 3, 3, 3, device=dev) * 0.05)
@@ -80,6 +103,15 @@ CASES = {
     "nt_trunk": lambda: [nt(864, 768, 3072), nt(864, 3072, 768), nt(864, 768, 768), nt(864, 2304, 768)],
     "nt_big": lambda: [nt(442368, 512, 128), nt(442368, 128, 512), nt(442368, 128, 32), nt(442368, 32, 128),
                        nt(6912, 128, 512), nt(1769472, 16, 64), nt(55296, 256, 64)],
+    "nt_model": lambda: [nt_model(442368, 512, 128, v) for v in ("plain", "stats", "dgrad")] +
+                        [nt_model(442368, 128, 32, v) for v in ("plain", "stats")] +
+                        [nt_model(442368, 32, 128, v) for v in ("plain", "dgrad")] +
+                        [nt_model(442368, 384, 128, "plain"), nt_model(442368, 128, 512, "plain"),
+                         nt_model(442368, 128, 384, "dgrad"), nt_model(55296, 1024, 256, "stats"),
+                         nt_model(55296, 256, 64, "stats"), nt_model(55296, 64, 256, "dgrad")],
+    "nt_debug": lambda: [(call("ctu_set_option", b"nt_debug", d), print("nt_debug =", d),
+                          nt_model(442368, 512, 128, "plain"), nt_model(442368, 128, 32, "plain"),
+                          nt_model(55296, 1024, 256, "plain"), call("ctu_set_option", b"nt_debug", 0)) for d in (0, 1, 2, 3)],
     "halo_fwd": lambda: [halo(2, 96, 96, 96, 64, 64, "fwd"), halo(2, 48, 48, 96, 128, 128, "fwd"),
                          halo(2, 24, 24, 48, 256, 256, "fwd"), halo(2, 48, 48, 96, 32, 32, "fwd"),
                          halo(2, 12, 12, 24, 512, 512, "fwd")],
