@@ -21,6 +21,8 @@
 #define HALO_W (HB_W + 2)
 #define HALO_VOX (HALO_D * HALO_H * HALO_W)  // 600
 
+int ctu_option_nt_debug();  // attention.hip
+
 struct HaloArgs {
   const void* x1;
   const void* x2;
@@ -33,6 +35,7 @@ struct HaloArgs {
   const void* residual;    // optional [rows][ldc] (same dtype): added to the result (bf16 DMA kernel, n_split == 0)
   float* part;             // split over input channels (small volumes): fp32 partial outputs [split][rows][ntn * 32], else NULL
   int hc_per_split;        // 16-channel half chunks per split (blockIdx.z)
+  int debug;               // measurement hook (ctu_set_option "nt_debug"): 1 = no output stores, 4 = no weight DMA, 8 = no halo DMA
 };
 
 template <typename T, int NT>
@@ -215,12 +218,18 @@ __global__ __launch_bounds__(256, RD == 2 ? 3 : 2) void conv3_halo_dma_kernel(co
   const bf16* x2 = reinterpret_cast<const bf16*>(p.x2);
   const bf16* wf = reinterpret_cast<const bf16*>(p.wfrag);
 
-  // ---- per-lane halo sources of this wave's DMA instructions (instruction i = wave + 4k fills slots 64 i ..) ----
-  int hm[5];
+  // ---- DMA roles.  vmcnt retires a wave's vector-memory operations IN ISSUE ORDER: if one wave issues a halo prefetch
+  // (needed nine stages later) and then weight stages (needed two stages later), every wait for those weights also waits
+  // for the halo gather - its HBM round trip lands on the critical path three stages after it was issued (measured: 22 %
+  // of the kernel at 128 -> 128 @ 48 x 48 x 96, 37 % at 64 -> 64 @ 96^3).  So wave 0 issues ALL halo instructions and
+  // nothing else - its one wait (vmcnt(0) at the first stage of a chunk) sees a prefetch that is nine stages old - and
+  // waves 1 - 3 issue the weight stages.
+  // per-lane halo sources of wave 0's DMA instructions (instruction k fills slots 64 k ..)
+  int hm[HINS];
   unsigned hpart = 0;
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int S = (wave + 4 * k) * 64 + lane;
+  for (int k = 0; k < HINS; ++k) {
+    const int S = k * 64 + lane;
     int m = -1;
     if (S < 2 * HALO_VOX) {
       const int vox = S >> 1, hs = S & 1;
@@ -233,10 +242,10 @@ __global__ __launch_bounds__(256, RD == 2 ? 3 : 2) void conv3_halo_dma_kernel(co
     }
     hm[k] = m;
   }
-  const int h_w = (HINS - wave + 3) >> 2;  // DMA instructions of this wave per halo half chunk / per weight stage
-  const int b_w = (SFR - wave + 3) >> 2;
+  constexpr int BW = SFR / 3;  // weight DMA instructions per loader wave (1 - 3) and stage: NT
 
-  auto issue_halo = [&](int hc) {
+  auto issue_halo = [&](int hc) {  // wave 0 only
+    if (p.debug & 8) return;
     const int c0 = hc * 16;
     const bool first = c0 < p.C1;
     const bf16* src = first ? x1 : x2;
@@ -244,26 +253,25 @@ __global__ __launch_bounds__(256, RD == 2 ? 3 : 2) void conv3_halo_dma_kernel(co
     const int cc = first ? c0 : c0 - p.C1;
     unsigned char* dst = smem + (hc & 1) * HBUF;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int i = wave + 4 * k;
-      if (i < HINS) {
-        const bf16* g = hm[k] >= 0 ? src + (size_t)hm[k] * cs + cc + ((hpart >> k) & 1) * 8
-                                   : reinterpret_cast<const bf16*>(g_zero16);
-        dma16(g, dst + i * 1024);
-      }
+    for (int k = 0; k < HINS; ++k) {
+      const bf16* g = hm[k] >= 0 ? src + (size_t)hm[k] * cs + cc + ((hpart >> k) & 1) * 8
+                                 : reinterpret_cast<const bf16*>(g_zero16);
+      dma16(g, dst + k * 1024);
     }
   };
   // weight stage = fragments f = wave, wave + 4, wave + 8 of this wave: per-lane byte offsets inside the stage are
   // fixed for the kernel, the stage's base address is wave-uniform -> one grouped DMA issue per stage (dma16_group)
-  unsigned bvoff[3];
+  // loader wave w (1 - 3) takes fragments f = (w - 1) + 3 k, k < NT: LDS destinations 3 KiB apart
+  unsigned bvoff[BW];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int f = wave + 4 * k, tapi = f / NT, j = f - tapi * NT;
+  for (int k = 0; k < BW; ++k) {
+    const int f = (wave > 0 ? wave - 1 : 0) + 3 * k, tapi = f / NT, j = f - tapi * NT;
     bvoff[k] = (unsigned)(((tapi * 2 * p.ntn + j) * 512 + lane * 8) * 2);
   }
-  auto issue_b = [&](int hc, int s, int slot) {
+  auto issue_b = [&](int hc, int s, int slot) {  // waves 1 - 3 only
+    if (p.debug & 4) return;
     const bf16* base = wf + ((size_t)(((hc >> 1) * 27 + 3 * s) * 2 + (hc & 1)) * p.ntn + nt0) * 512;
-    dma16_group(b_w, base, bvoff[0], bvoff[1], bvoff[2], smem + RING0 + slot * SBYTES + wave * 1024);
+    dma16_groupN<BW, 3072>(base, bvoff, smem + RING0 + slot * SBYTES + (wave - 1) * 1024);
   };
 
   f32x16 acc[2][NT];
@@ -277,22 +285,29 @@ __global__ __launch_bounds__(256, RD == 2 ? 3 : 2) void conv3_halo_dma_kernel(co
   int vrow, vcol;
   halo_row_to_hw(r, vrow, vcol);
 
-  issue_halo(hc_b);
-  issue_b(hc_b, 0, 0);
-  if (RD == 3) issue_b(hc_b, 1, 1);
+  if (wave == 0) {
+    issue_halo(hc_b);
+  } else {
+    issue_b(hc_b, 0, 0);
+    if (RD == 3) issue_b(hc_b, 1, 1);
+  }
   int hc = hc_b, s = 0, rs = 0;               // stage being computed: half chunk, (td, th) index, ring slot
   int ihc = hc_b, is = RD - 1, irs = RD - 1;  // stage being fetched (RD - 1 ahead)
   for (int u = 0; u < U; ++u) {
-    // own DMAs of this stage (and, being older, of its halo) have landed; still in flight: the RD - 2 younger weight
-    // stages and a halo prefetch issued in one of the last RD - 1 stages (it is issued after that stage's weights)
-    const bool halo_in_flight = (s == 1 || (RD == 3 && s == 2)) && hc + 1 < HC;
-    wait_vm_then_barrier_n((RD - 2) * b_w + (halo_in_flight ? h_w : 0));
-    issue_b(ihc, is, irs);  // past the end: refetches the last stage into a slot nobody reads (keeps the counts)
+    if (wave == 0) {
+      // the halo of this chunk (issued nine stages ago, the only vector-memory traffic of this wave) has landed
+      if (s == 0) wait_vm_then_barrier<0>();
+      else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (s == 0 && hc + 1 < HC) issue_halo(hc + 1);  // into the buffer whose last readers passed this barrier
+    } else {
+      // own weight DMAs of this stage have landed; still in flight: the RD - 2 younger stages
+      wait_vm_then_barrier<(RD - 2) * BW>();
+      issue_b(ihc, is, irs);  // past the end: refetches the last stage into a slot nobody reads (keeps the counts)
+    }
     if (u + RD < U) {
       if (++is == 9) { is = 0; ++ihc; }
     }
     irs = irs == RD - 1 ? 0 : irs + 1;
-    if (s == 0 && hc + 1 < HC) issue_halo(hc + 1);
 
     const int td = (s * 11) >> 5, th = s - 3 * td;
     const unsigned char* hb = smem + (hc & 1) * HBUF;
@@ -400,7 +415,7 @@ __global__ __launch_bounds__(256, RD == 2 ? 3 : 2) void conv3_halo_dma_kernel(co
 #pragma unroll
               for (int e = 0; e < 8; ++e) xv[e] += rr[e];
             }
-            store8(out + m * p.ldc + n, xv);
+            if (!(p.debug & 1)) store8(out + m * p.ldc + n, xv);
           }
         }
       }
@@ -480,6 +495,7 @@ template <> struct HaloDma<bf16> {
       if (ksplit < 2) ksplit = 1;
     }
     HaloArgs q = p;
+    q.debug = ctu_option_nt_debug();
     q.hc_per_split = (HCT + ksplit - 1) / ksplit;
     ksplit = (HCT + q.hc_per_split - 1) / q.hc_per_split;
     q.part = ksplit > 1 ? ws : nullptr;

@@ -75,7 +75,7 @@ template <int IPW, int MAXA, int EXTRA = 0> __device__ __forceinline__ void wait
 // BK = 32 serves K % 64 == 32 (the 32-channel layers): 64-B LDS rows, four to a bank row, slot ^ ((row >> 2) & 3).
 template <int BM, int BN, int R, bool BT, int BK = 64>
 __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) void gemm_nt_dma_kernel(const GemmNtArgs p) {
-  static_assert(BK == 64 || (BK == 32 && !BT), "stage depth");
+  static_assert(BK == 64 || BK == 128 || (BK == 32 && !BT), "stage depth");
   constexpr int ROWB = BK * 2;         // bytes of a tile row in LDS
   constexpr int SPR = BK / 8;          // 16-B slots per row
   constexpr int RPI = 1024 / ROWB;     // tile rows per DMA wave-instruction
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
   constexpr int EPI_LD = 32 + 4;
   constexpr int EPI_BYTES = 4 * 16 * EPI_LD * 4;
   constexpr int IPW = APW + BPW;   // DMA instructions per wave and stage
-  static_assert((R - 2) * IPW <= 8, "counted vmcnt switch covers 0..8");
+  static_assert((R - 2) * IPW + 8 <= 63, "vmcnt is a 6-bit count");
   constexpr int RED_BYTES = 4 * WN * 2 * 4;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[R * STAGE + EPI_BYTES + RED_BYTES];
 
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
   const int wm = wave >> 1, wn = wave & 1;
   const int vid = xcd_remap(blockIdx.x, gridDim.x);
   // source-side bank swizzle of a tile row's 16-B slots (conflict-free ds_read_b128 of 32-row fragments)
-  auto swz = [](int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; };
+  auto swz = [](int row) { return BK == 128 ? row & 15 : BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; };
 
   // Work items = (m tile, n tile, k split), n fastest.  The grid is a multiple of cols = tiles_n * splitk (launcher), so a
   // persistent workgroup keeps its (n tile, k split) for life and only walks down the m tiles: no division per item (the
@@ -128,9 +128,9 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
 #pragma unroll
   for (int j = 0; j < BPW; ++j) {
     if constexpr (BT) {  // instruction (panel, 16-row group): brow = k row inside the stage, bslot = first column
-      const int ins = BPW * wave + j;
-      brow[j] = (ins & 3) * 16 + (lane >> 2);
-      bslot[j] = (ins >> 2) * 32 + (lane & 3) * 8;
+      const int ins = BPW * wave + j;  // BK / 16 instructions (16 k rows x 32 columns each) per 32-column panel
+      brow[j] = (ins % (BK / 16)) * 16 + (lane >> 2);
+      bslot[j] = (ins / (BK / 16)) * 32 + (lane & 3) * 8;
     } else {
       brow[j] = RPI * (BPW * wave + j) + lane / SPR;
       bslot[j] = (lane % SPR) ^ swz(brow[j]);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int row = wn * WN + j * 32 + r;
-    if constexpr (BT) boff[j] = A_BYTES + (wn * NJ + j) * 4096 + (h * 8 * 32 + r) * 2;  // panel, k row 8 h, column r
+    if constexpr (BT) boff[j] = A_BYTES + (wn * NJ + j) * (BK * 64) + (h * 8 * 32 + r) * 2;  // panel, k row 8 h, column r
     else boff[j] = A_BYTES + row * ROWB + ((h ^ swz(row)) << 4);
   }
 
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_stream_kernel(const GemmNtArgs
 static bool stream_ok(const GemmNtArgs& p) {
   const ctu_epilogue& e = p.ep;
   return (p.K == 32 || p.K == 64 || p.K == 128) && p.a2 == nullptr && p.C1 == p.K && p.N % 128 == 0 && p.M % 128 == 0 &&
-         p.M >= 128 * 1024 && p.splitk <= 1 && !e.bias && e.act == 0 && !e.pre_out && !e.scatter && e.n_split <= 0 &&
+         p.M >= 128 * 256 && p.splitk <= 1 && !e.bias && e.act == 0 && !e.pre_out && !e.scatter && e.n_split <= 0 &&
          (!p.in_acc || (p.in_rows % 128 == 0 && !e.residual)) && !getenv("CTU_NT_NO_STREAM");
 }
 static void launch_stream(const GemmNtArgs& p, hipStream_t stream) {
@@ -677,7 +677,11 @@ int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {
   }
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  p.ksteps = p.K / (bk32 ? 32 : 64);
+  // 64 x 64 tiles (the 864-token ViT trunk: a handful of MFMAs per 64-deep stage, the stage hand-over dominates) take
+  // 128-deep stages when K allows: half the barriers and waits per tile, 8 MFMAs per wave between them
+  const bool bk128 = !bk32 && BM == 64 && BN == 64 && p.K % 128 == 0 && p.K >= 512 && (!p.a2 || p.C1 % 128 == 0) &&
+                     !getenv("CTU_NT_NO_BK128");
+  p.ksteps = p.K / (bk32 ? 32 : bk128 ? 128 : 64);
   if (p.splitk > p.ksteps) p.splitk = p.ksteps;
   if (p.splitk < 1) p.splitk = 1;
   p.ks_per_split = (p.ksteps + p.splitk - 1) / p.splitk;
@@ -695,6 +699,9 @@ int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {
     if (p.w_kn) return -1;
     if (BN == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 64, 3, false, 32>), g, b, 0, stream, p);
     else hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128, 3, false, 32>), g, b, 0, stream, p);
+  } else if (bk128) {
+    if (p.w_kn) hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 64, 3, true, 128>), g, b, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 64, 3, false, 128>), g, b, 0, stream, p);
   } else if (p.w_kn) {
     if (BM == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 64, 4, true>), g, b, 0, stream, p);
     else if (BN == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 64, 2, true>), g, b, 0, stream, p);

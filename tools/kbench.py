@@ -109,6 +109,12 @@ CASES = {
                         [nt_model(442368, 384, 128, "plain"), nt_model(442368, 128, 512, "plain"),
                          nt_model(442368, 128, 384, "dgrad"), nt_model(55296, 1024, 256, "stats"),
                          nt_model(55296, 256, 64, "stats"), nt_model(55296, 64, 256, "dgrad")],
+    "halo_debug": lambda: [(call("ctu_set_option", b"nt_debug", d), print("nt_debug =", d),
+                            halo(2, 96, 96, 96, 64, 64, "fwd"), halo(2, 48, 48, 96, 128, 128, "fwd"),
+                            halo(2, 24, 24, 48, 256, 256, "fwd"), call("ctu_set_option", b"nt_debug", 0)) for d in (0, 4, 8, 12)],
+    "nt_small": lambda: [nt_model(55296, 256, 64, "stats", sets=8), nt_model(55296, 256, 64, "plain", sets=8),
+                         nt_model(6912, 512, 128, "stats", sets=16), nt_model(6912, 512, 128, "plain", sets=16),
+                         nt_model(6912, 128, 128, "plain", sets=16), nt_model(55296, 128, 64, "plain", sets=8)],
     "nt_debug": lambda: [(call("ctu_set_option", b"nt_debug", d), print("nt_debug =", d),
                           nt_model(442368, 512, 128, "plain"), nt_model(442368, 128, 32, "plain"),
                           nt_model(55296, 1024, 256, "plain"), call("ctu_set_option", b"nt_debug", 0)) for d in (0, 1, 2, 3)],
