@@ -73,6 +73,45 @@ def nt_model(M, N, K, variant, sets=4, B=2):
     report(f"igemm_nt[{variant}] M={M} N={N} K={K}", us, 2.0 * M * N * K, 2.0 * (M * (N + K) + N * K) + extra)
 
 
+def inorm(B, D, H, W, C, sets=3):
+    """InstanceNorm kernels on rotating tensors (beyond the Infinity Cache): forward apply (with stats from a fused conv
+    this is all the forward does), backward reduce and backward apply."""
+    xs = [torch.randn(B, D, H, W, C, device=dev, dtype=DT) for _ in range(sets)]
+    gs = [torch.randn(B, D, H, W, C, device=dev, dtype=DT) for _ in range(sets)]
+    ys = [torch.empty_like(x) for x in xs]
+    S = D * H * W
+    stats = torch.randn(B, C, 2, device=dev).abs() + 0.5
+    sums = torch.zeros(B * C * 2, device=dev, dtype=torch.float64)
+    dirty = torch.zeros(B * C * 2, device=dev, dtype=torch.float64)
+    it = [0]
+    nb = B * S * C * 2.0
+
+    def nxt():
+        it[0] = (it[0] + 1) % sets
+        return it[0]
+
+    def f_apply():
+        i = nxt()
+        call("ctu_in_apply", dcode(DT), ptr(xs[i]), ptr(stats), None, ptr(ys[i]), B, S, C, 1, stream())
+
+    def f_stats():
+        i = nxt()
+        call("ctu_in_stats", dcode(DT), ptr(xs[i]), B, S, C, ptr(sums), ptr(stats), stream())
+
+    def f_red():
+        i = nxt()
+        call("ctu_in_bwd_reduce", dcode(DT), ptr(gs[i]), ptr(xs[i]), None, ptr(stats), ptr(sums), B, S, C, 1, stream())
+
+    def f_bapply():
+        i = nxt()
+        call("ctu_in_bwd_apply", dcode(DT), ptr(gs[i]), ptr(xs[i]), None, ptr(stats), ptr(sums), ptr(ys[i]), None, B, S, C, 1,
+             ptr(dirty), B * C * 2, stream())
+    tag = f"{C}ch @{D}x{H}x{W} B{B}"
+    report(f"in_apply       {tag}", timeit(f_apply), 0, 2 * nb)
+    report(f"in_bwd_reduce  {tag}", timeit(f_red), 0, 2 * nb)
+    report(f"in_bwd_apply   {tag}", timeit(f_bapply), 0, 3 * nb)
+
+
 def halo(B, D, H, W, C, N, what):
     x = torch.randn(B, D, H, W, C, device=dev, dtype=DT)
     w = torch.nn.Parameter(torch.randn(N, C, 3, 3, 3, device=dev) * 0.05)
@@ -112,6 +151,8 @@ CASES = {
     "halo_debug": lambda: [(call("ctu_set_option", b"nt_debug", d), print("nt_debug =", d),
                             halo(2, 96, 96, 96, 64, 64, "fwd"), halo(2, 48, 48, 96, 128, 128, "fwd"),
                             halo(2, 24, 24, 48, 256, 256, "fwd"), call("ctu_set_option", b"nt_debug", 0)) for d in (0, 4, 8, 12)],
+    "inorm": lambda: [inorm(2, 96, 96, 96, 64), inorm(2, 48, 48, 96, 128), inorm(2, 48, 48, 96, 512), inorm(2, 24, 24, 48, 256),
+                      inorm(2, 24, 24, 48, 1024), inorm(2, 48, 48, 96, 32)],
     "nt_small": lambda: [nt_model(55296, 256, 64, "stats", sets=8), nt_model(55296, 256, 64, "plain", sets=8),
                          nt_model(6912, 512, 128, "stats", sets=16), nt_model(6912, 512, 128, "plain", sets=16),
                          nt_model(6912, 128, 128, "plain", sets=16), nt_model(55296, 128, 64, "plain", sets=8)],
