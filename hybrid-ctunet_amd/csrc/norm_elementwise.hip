@@ -501,9 +501,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_stage2_kernel(const float* 
   __shared__ float red[16][17];
   const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + cl;  // index into the [2][dim] row of a partial
+  // blockIdx.y splits the partial rows: with dim = 32 .. 128 (the per-voxel LayerNorms, 1024 partial rows) four to
+  // sixteen workgroups walking 64 rows each took 11.6 us per launch, 52 launches per step
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
   float acc = 0.f;
   if (i < 2 * dim)
-    for (int b = rg; b < nblk; b += 16) acc += ws[(size_t)b * 2 * dim + i];
+    for (int b = b0 + rg; b < b1; b += 16) acc += ws[(size_t)b * 2 * dim + i];
   red[rg][cl] = acc;
   __syncthreads();
   if (rg == 0 && i < 2 * dim) {
@@ -512,7 +516,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_stage2_kernel(const float* 
     for (int r = 0; r < 16; ++r) t += red[r][cl];
     const int which = i / dim, col = i - which * dim;
     float* dst = which ? dbeta : dgamma;
-    dst[col] += t;
+    if (gridDim.y > 1) atomicAdd(&dst[col], t);
+    else dst[col] += t;
   }
 }
 
@@ -534,8 +539,9 @@ extern "C" int ctu_layernorm_bwd(ctu_dtype dtype, const void* dy, const void* x,
     default: CTU_DISPATCH(dtype, LN_BWD(float, 4), LN_BWD(bf16, 4)); break;
   }
 #undef LN_BWD
-  hipLaunchKernelGGL(layernorm_bwd_stage2_kernel, dim3((2 * dim + 15) / 16), dim3(256), 0, s, ws, dgamma, dbeta, (int)grid,
-                     dim);
+  const unsigned ysplit = grid >= 256 ? 8 : (grid >= 64 ? 2 : 1);
+  hipLaunchKernelGGL(layernorm_bwd_stage2_kernel, dim3((2 * dim + 15) / 16, ysplit), dim3(256), 0, s, ws, dgamma, dbeta,
+                     (int)grid, dim);
   return ctu_check_launch("layernorm_bwd");
 }
 
