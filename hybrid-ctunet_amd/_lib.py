@@ -60,6 +60,7 @@ _SIGS = {
     "ctu_in_bwd_apply": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i32, _vp],
     "ctu_layernorm_fwd": [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "ctu_layernorm_bwd": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    "ctu_layernorm_bwd_add": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "ctu_gelu_fwd": [_i32, _vp, _vp, _i64, _vp],
     "ctu_gelu_bwd": [_i32, _vp, _vp, _vp, _i64, _vp],
     "ctu_add": [_i32, _vp, _vp, _vp, _i64, _vp],

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean_rstd, T* __restrict__ dx,
                                                             float* __restrict__ ws, const int64_t rows, const int dim,
-                                                            const int lpr, const int vpl) {
+                                                            const int lpr, const int vpl, const T* __restrict__ dx_add) {
   const int tid = threadIdx.x;
   const int rows_per_block = 256 / lpr;
   const int sub = tid % lpr, rloc = tid / lpr;
@@ -436,6 +436,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = rstd * (g[k][e] - m1 - xh[k][e] * m2);
+        if (dx_add) {  // gradient that reached x through the residual branch around this LayerNorm (ops.GradStash)
+          float a[8];
+          load8(dx_add + (size_t)row * dim + c0, a);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += a[e];
+        }
         store8(dx + (size_t)row * dim + c0, o);
       }
   }
@@ -521,9 +527,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_stage2_kernel(const float* 
   }
 }
 
+extern "C" int ctu_layernorm_bwd_add(ctu_dtype dtype, const void* dy, const void* x, const float* gamma,
+                                     const float* mean_rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta,
+                                     float* ws, int64_t rows, int32_t dim, ctu_stream_t stream);
 extern "C" int ctu_layernorm_bwd(ctu_dtype dtype, const void* dy, const void* x, const float* gamma,
                                  const float* mean_rstd, void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows,
                                  int32_t dim, ctu_stream_t stream) {
+  return ctu_layernorm_bwd_add(dtype, dy, x, gamma, mean_rstd, nullptr, dx, dgamma, dbeta, ws, rows, dim, stream);
+}
+extern "C" int ctu_layernorm_bwd_add(ctu_dtype dtype, const void* dy, const void* x, const float* gamma,
+                                     const float* mean_rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta,
+                                     float* ws, int64_t rows, int32_t dim, ctu_stream_t stream) {
   int lpr, vpl;
   if (int rc = ln_config(dim, &lpr, &vpl)) return rc;
   CTU_REQUIRE(dy && x && gamma && mean_rstd && dx && dgamma && dbeta && ws && rows > 0, "null pointer / bad rows");
@@ -531,7 +545,7 @@ extern "C" int ctu_layernorm_bwd(ctu_dtype dtype, const void* dy, const void* x,
   hipStream_t s = (hipStream_t)stream;
 #define LN_BWD(T, V)                                                                                                  \
   hipLaunchKernelGGL((layernorm_bwd_kernel<T, V>), dim3(grid), dim3(256), 0, s, (const T*)dy, (const T*)x, gamma, mean_rstd, \
-                     (T*)dx, ws, rows, dim, lpr, vpl)
+                     (T*)dx, ws, rows, dim, lpr, vpl, (const T*)dx_add)
   switch (vpl) {
     case 1: CTU_DISPATCH(dtype, LN_BWD(float, 1), LN_BWD(bf16, 1)); break;
     case 2: CTU_DISPATCH(dtype, LN_BWD(float, 2), LN_BWD(bf16, 2)); break;

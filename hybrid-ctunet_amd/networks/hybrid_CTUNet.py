@@ -222,7 +222,7 @@ class MultiAxisAttention(nn.Module):
         self.register_buffer('rel_pos_indices', (rel_pos * torch.tensor([m * m, m, 1])).sum(dim=-1), persistent=False)
 
     def forward(self, x, residual=None, part=1):
-        h = ops.layer_norm(x, self.norm.weight, self.norm.bias)
+        h, residual = ops.norm_with_residual(x, residual, self.norm.weight, self.norm.bias)
         qkv = ops.linear(h, self.to_qkv.weight)
         p = self.to_out[1].p if self.training else 0.0
         o = ops.attention(qkv, self.heads, self.scale, self.rel_pos_bias.weight, part, self.window_size, dropout_p=p)

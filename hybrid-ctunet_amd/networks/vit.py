@@ -41,7 +41,7 @@ def feed_forward(n, x, residual, training):
     """LayerNorm -> Linear -> GELU -> Dropout -> Linear -> Dropout (+ residual) on the parameter holders of `n`.  The
     dropout-free case keeps the residual in the second GEMM's epilogue."""
     p1, p2 = (n[3].p, n[5].p) if training else (0.0, 0.0)
-    h = ops.layer_norm(x, n[0].weight, n[0].bias)
+    h, residual = ops.norm_with_residual(x, residual, n[0].weight, n[0].bias)
     h = ops.linear(h, n[1].weight, n[1].bias, None, 1)
     if p1 > 0.0:
         h = ops.dropout(h, p1)
@@ -71,7 +71,7 @@ class Attention(nn.Module):
 
     def forward(self, x, residual=None):
         p = self.dropout.p if self.training else 0.0
-        h = ops.layer_norm(x, self.norm.weight, self.norm.bias)
+        h, residual = ops.norm_with_residual(x, residual, self.norm.weight, self.norm.bias)
         qkv = ops.linear(h, self.to_qkv.weight)
         o = ops.attention(qkv, self.heads, self.scale, dropout_p=p)
         if p > 0.0:

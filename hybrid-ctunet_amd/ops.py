@@ -754,8 +754,9 @@ class LayerNormFn(torch.autograd.Function):
     """nn.LayerNorm(dim), eps 1e-5 (vit.py:35,55,116,118; hybrid_CTUNet.py:456,518,630-631)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta):
+    def forward(ctx, x, gamma, beta, grad_stash=None):
         _check_act(x)
+        ctx.grad_stash = grad_stash
         dim = x.shape[-1]
         rows = x.numel() // dim
         y = torch.empty_like(x)
@@ -779,16 +780,35 @@ class LayerNormFn(torch.autograd.Function):
             gb_buf = gb = torch.zeros(dim, dtype=torch.float32, device=x.device)
             gg_done = gb_done = None
         ws = torch.empty(1024 * 2 * dim, dtype=torch.float32, device=x.device)  # CTU_LN_BWD_MAX_BLOCKS partial rows
-        call("ctu_layernorm_bwd", dcode(x.dtype), ptr(gy), ptr(x), ptr(gamma), ptr(mr), ptr(gx), ptr(gg_buf), ptr(gb_buf),
-             ptr(ws), rows, dim, stream())
+        # gradient that reached x around the norm (residual branch, GradStash): added while dx is written
+        extra = ctx.grad_stash.pop() if ctx.grad_stash else None
+        if extra is not None and (extra.shape != x.shape or extra.dtype != x.dtype or not extra.is_contiguous()):
+            extra = extra.to(x.dtype).contiguous().view_as(x)
+        call("ctu_layernorm_bwd_add", dcode(x.dtype), ptr(gy), ptr(x), ptr(gamma), ptr(mr), ptr(extra), ptr(gx), ptr(gg_buf),
+             ptr(gb_buf), ptr(ws), rows, dim, stream())
         if gg_done is not None:
             gg_done()
             gb_done()
-        return gx, gg, gb
+        return gx, gg, gb, None
 
 
-def layer_norm(x, gamma, beta):
-    return LayerNormFn.apply(x, gamma, beta)
+def layer_norm(x, gamma, beta, grad_stash=None):
+    return LayerNormFn.apply(x, gamma, beta, grad_stash)
+
+
+LN_STASH = not os.environ.get("CTU_NO_LN_STASH")  # (A/B switch for measurements)
+
+
+def norm_with_residual(x, residual, gamma, beta):
+    """(LayerNorm(x), residual') for the pre-norm residual pattern `f(LN(x)) + x` (residual is x): the residual is routed
+    through GradStash so that its gradient joins the LayerNorm backward's dx instead of being added by autograd.  The
+    stash node is created after the norm's node; its backward runs when the block's last op hands back the residual
+    gradient, long before the norm's own backward."""
+    if residual is x and x.requires_grad and torch.is_grad_enabled() and LN_STASH:
+        stash = []
+        h = layer_norm(x, gamma, beta, stash)
+        return h, GradStash.apply(x, stash)
+    return layer_norm(x, gamma, beta), residual
 
 
 class AddBcastFn(torch.autograd.Function):

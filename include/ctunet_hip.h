@@ -199,6 +199,12 @@ int ctu_layernorm_fwd(ctu_dtype dtype, const void* x, const float* gamma, const 
 #define CTU_LN_BWD_MAX_BLOCKS 1024
 int ctu_layernorm_bwd(ctu_dtype dtype, const void* dy, const void* x, const float* gamma, const float* mean_rstd,
                       void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int32_t dim, ctu_stream_t stream);
+/* dx = LayerNorm backward + dx_add (same shape / dtype as dx, may be NULL): the gradient that reached x through the
+ * residual branch around the norm (x = f(LN(x)) + x, vit.py:93-96, hybrid_CTUNet.py:434-440) joins here instead of in an
+ * elementwise pass of autograd. */
+int ctu_layernorm_bwd_add(ctu_dtype dtype, const void* dy, const void* x, const float* gamma, const float* mean_rstd,
+                          const void* dx_add, void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int32_t dim,
+                          ctu_stream_t stream);
 
 /* K12 GELU (exact erf) and plain adds (vit.py:37; hybrid_CTUNet.py:520; Residual :434-440). n multiple of 8. */
 int ctu_gelu_fwd(ctu_dtype dtype, const void* x, void* y, int64_t n, ctu_stream_t stream);
