@@ -574,6 +574,7 @@ struct HaloWgArgs {
   float* dw;  // [27][N][K]
   int B, D, H, W, C1, C2, N;
   int nbd, nbh, nbw, nbricks, bricks_per_block, tiles_c, tiles_n;
+  int debug;  // measurement hook (ctu_set_option "nt_debug"): 4 = no operand DMA
 };
 
 template <typename T>
@@ -715,6 +716,7 @@ __global__ __launch_bounds__(512, 1) void conv3_halo_wgrad_dma_kernel(const Halo
   }
 
   auto issue = [&](int brick, int buf) {
+    if (p.debug & 4) return;
     int t = brick;
     const int bw = t % p.nbw; t /= p.nbw;
     const int bh = t % p.nbh; t /= p.nbh;
@@ -805,6 +807,7 @@ extern "C" int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void*
   CTU_REQUIRE(C1 > 0 && C1 % 32 == 0 && C2 >= 0 && C2 % 32 == 0 && (C2 == 0 || x2), "conv3_halo_wgrad: C1, C2 %% 32");
   CTU_REQUIRE(N > 0 && N % 8 == 0, "conv3_halo_wgrad: N %% 8");
   HaloWgArgs p;
+  p.debug = ctu_option_nt_debug();
   p.dy = dy; p.x1 = x1; p.x2 = x2; p.dw = dw;
   p.B = B; p.D = D; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.N = N;
   p.nbd = (D + HB_D - 1) / HB_D; p.nbh = (H + HB_H - 1) / HB_H; p.nbw = (W + HB_W - 1) / HB_W;

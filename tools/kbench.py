@@ -153,6 +153,9 @@ CASES = {
                             halo(2, 24, 24, 48, 256, 256, "fwd"), call("ctu_set_option", b"nt_debug", 0)) for d in (0, 4, 8, 12)],
     "inorm": lambda: [inorm(2, 96, 96, 96, 64), inorm(2, 48, 48, 96, 128), inorm(2, 48, 48, 96, 512), inorm(2, 24, 24, 48, 256),
                       inorm(2, 24, 24, 48, 1024), inorm(2, 48, 48, 96, 32)],
+    "wgrad_debug": lambda: [(call("ctu_set_option", b"nt_debug", d), print("nt_debug =", d),
+                             halo(2, 96, 96, 96, 64, 64, "wgrad"), halo(2, 48, 48, 96, 128, 128, "wgrad"),
+                             halo(2, 24, 24, 48, 256, 256, "wgrad"), call("ctu_set_option", b"nt_debug", 0)) for d in (0, 4)],
     "nt_small": lambda: [nt_model(55296, 256, 64, "stats", sets=8), nt_model(55296, 256, 64, "plain", sets=8),
                          nt_model(6912, 512, 128, "stats", sets=16), nt_model(6912, 512, 128, "plain", sets=16),
                          nt_model(6912, 128, 128, "plain", sets=16), nt_model(55296, 128, 64, "plain", sets=8)],
