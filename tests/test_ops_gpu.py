@@ -78,6 +78,30 @@ def test_linear(ops, dtype, M, K, N, bias, act, res, gemm):
         ops.USE_W_KN = True
 
 
+@pytest.mark.parametrize("M,K,N,res", [(32768, 128, 256, False), (32768 + 128 * 37, 64, 128, True), (40960, 32, 384, False),
+                                       (32768, 128, 128, True)])
+def test_linear_stream_kernel(ops, M, K, N, res):
+    """The short-K long-M layers (M >= 32768, K in {32, 64, 128}, N % 128 == 0) run on gemm_nt_stream: forward (plain and
+    with a residual in the epilogue) and, through the data gradient of a Linear whose forward weight is read reduction-major,
+    its w_kn form (here: K_bwd = N_fwd = 128 for the last case; the other cases' data gradients have K_bwd = N_fwd >= 256
+    and stay on the general kernel).  Checked against float64 math like every other GEMM case, and against the general
+    kernel (CTU_NT_NO_STREAM) for equal rounding."""
+    import os
+    dtype = torch.bfloat16
+    _linear_case(ops, dtype, M, K, N, False, 0, res)
+    x = rnd((M, K), 1).to(dtype).cuda()
+    w = rnd((N, K), 2, 1 / math.sqrt(K)).float().cuda()
+    r = rnd((M, N), 4).to(dtype).cuda() if res else None
+    with torch.no_grad():
+        a = ops.linear(x, w, None, r, 0)
+        os.environ["CTU_NT_NO_STREAM"] = "1"
+        try:
+            b = ops.linear(x, w, None, r, 0)
+        finally:
+            os.environ.pop("CTU_NT_NO_STREAM", None)
+    assert torch.equal(a, b)      # same products, same fp32 accumulation order over k, same single rounding to bf16
+
+
 def _linear_case(ops, dtype, M, K, N, bias, act, res):
     x, xh = dev(rnd((M, K), 1), dtype, True)
     w, wh = dev(rnd((N, K), 2, 1 / math.sqrt(K)), torch.float32, True)
@@ -185,10 +209,13 @@ def test_conv_instance_norm_fused_statistics(ops, case, fused):
         ops.FUSE_IN_STATS = True
 
 
-@pytest.mark.parametrize("case", [(2, 4, 8, 8, 64, 256), (2, 8, 8, 8, 128, 72), (1, 2, 8, 8, 192, 64)])
+@pytest.mark.parametrize("case", [(2, 4, 8, 8, 64, 256), (2, 8, 8, 8, 128, 72), (1, 2, 8, 8, 192, 64),
+                                  (2, 16, 32, 32, 128, 256), (3, 16, 16, 48, 32, 128), (2, 24, 32, 32, 64, 384)])
 def test_conv1x1_instance_norm_fused_statistics(ops, case):
     """bf16 1x1x1 conv (plain GEMM) -> InstanceNorm: statistics summed in the LDS-DMA GEMM epilogue (ctu_epilogue.in_acc)
-    vs the float64 reference; rows per batch item are multiples of 128, N with a partial last tile included."""
+    vs the float64 reference; rows per batch item are multiples of 128, N with a partial last tile included.  The last three
+    cases (M >= 32768, K in {128, 32, 64}, N % 128 == 0) run on gemm_nt_stream: per-lane partial sums across a workgroup's
+    tile range, batch-item switches inside a range (3 items over 288 tiles), DPP reduction at the flush."""
     B, D, H, W, K, N = case
     dtype = torch.bfloat16
     x, xh = dev(cl(rnd((B, K, D, H, W), 1)) + 0.25, dtype, True)
