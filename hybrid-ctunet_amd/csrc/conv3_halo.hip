@@ -488,8 +488,13 @@ template <> struct HaloDma<bf16> {
     int ksplit = 1;
     const int64_t rows = (int64_t)p.B * p.D * p.H * p.W;
     if (ws && !p.residual && blocks < 256 && rows <= 16384 && HCT >= 4 && p.n_split == 0 && p.N % 8 == 0 && p.N <= 2048 && p.ldc % 8 == 0) {
-      ksplit = (512 + blocks - 1) / blocks;
-      if (ksplit > HCT / 2) ksplit = HCT / 2;  // at least two half chunks (18 stages) per workgroup
+      // fill the 512 resident slots (2 workgroups per CU) ONCE: rounding up (540 workgroups for 512 -> 512 @ 12 x 12 x 24)
+      // costs a second round for a handful of stragglers; down to one half chunk (9 stages) per workgroup if need be
+      // (256 -> 256 @ 6 x 6 x 12: 72.6 -> 28.1 us)
+      const int slots = getenv("CTU_HALO_KSPLIT_OLD") ? 0 : 512;
+      ksplit = slots ? slots / blocks : (512 + blocks - 1) / blocks;
+      const int kmax = slots ? HCT : HCT / 2;
+      if (ksplit > kmax) ksplit = kmax;
       const int64_t cap = ws_floats / (rows * ntn * 32);
       if (ksplit > cap) ksplit = (int)cap;
       if (ksplit < 2) ksplit = 1;
