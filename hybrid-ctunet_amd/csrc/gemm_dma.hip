@@ -638,7 +638,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_stream_kernel(const GemmNtArgs
     after_store = !(p.debug & 1);
     slot = slot + 1 == R ? 0 : slot + 1;
   }
-  if (STATS && stat_b >= 0) stat_flush();
+  if (STATS && stat_b >= 0) {
+    // the flush scratch aliases wave 0's store staging tile: every wave must be through its last epilogue first (the
+    // flushes inside the loop sit behind the loop-top barrier; without this one a fast wave's partial sums could land in
+    // the tile wave 0 was still reading back - rare garbage / NaN rows in the last tile of a workgroup's range)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    stat_flush();
+  }
 }
 
 static bool stream_ok(const GemmNtArgs& p) {

@@ -449,8 +449,13 @@ class CTUNet(_VitBranch):
 
     def forward(self, x_in):
         x = self._input(x_in)
-        vit_enc, vit_logits, vit_96x96 = self._vit_forward(x)
+        # The two encoders are independent; the reference runs the ViT branch first (hybrid_CTUNet.py:839-846).  Autograd
+        # replays later-built nodes first, so with that order the ViT trunk - half of all parameters, finished within a few
+        # milliseconds - would be the LAST gradients to become ready and its 350 MB all-reduce would sit exposed behind the
+        # backward pass.  ResNet first: in backward the ViT branch finishes early and the long convnet backward, which
+        # releases its gradients layer by layer down to the small stem, hides the communication (train.DataParallel).
         res_enc1, res_enc2, res_enc3, res_enc4 = self.convnet(x)
+        vit_enc, vit_logits, vit_96x96 = self._vit_forward(x)
         res_dec3 = self.res_decoder3(res_enc4, res_enc3, vit_enc[1])
         res_dec2 = self.res_decoder2(res_dec3, res_enc2, vit_enc[2])
         res_dec1 = self.res_decoder1(res_dec2, res_enc1, vit_enc[3])

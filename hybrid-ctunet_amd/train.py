@@ -370,12 +370,14 @@ class DataParallel(nn.Module):
 
 
 def gradient_ready_order(model: nn.Module) -> List[nn.Parameter]:
-    """Parameters in the order autograd finishes them for CTUNet/CUNet/TUNet (measured on the
-    reference): res heads -> res decoders 0..3 -> convnet (deep to shallow) -> vit heads/decoder -> vit_encoder ->
-    vit_encoder0 -> vit.  Modules not present are skipped; anything unlisted goes last."""
+    """Parameters in the order autograd finishes them for CTUNet/CUNet/TUNet as built here: res heads -> res decoders
+    0..3 -> vit heads/decoder -> vit_encoder -> vit_encoder0 -> vit -> convnet (deep to shallow).  (The reference builds
+    the ViT branch before the ResNet and therefore finishes it last; CTUNet.forward here swaps the two
+    independent encoders so that the parameter-heavy ViT trunk is not the tail of the backward pass.)  Modules not present
+    are skipped; anything unlisted goes last."""
     prefixes = ["res_out_24x24", "res_out_48x48", "res_out", "res_decoder0", "res_decoder1", "res_decoder2",
-                "res_decoder3", "convnet.layer4", "convnet.layer3", "convnet.layer2", "convnet.layer1", "convnet",
-                "decoder_linear_96x96", "vit_out", "vit_decoder0", "vit_encoder.", "vit_encoder0", "vit."]
+                "res_decoder3", "decoder_linear_96x96", "vit_out", "vit_decoder0", "vit_encoder.", "vit_encoder0", "vit.",
+                "convnet.layer4", "convnet.layer3", "convnet.layer2", "convnet.layer1", "convnet"]
     named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
     taken, out = set(), []
     for pre in prefixes:

@@ -66,3 +66,45 @@ def test_two_ranks_on_one_gpu_stay_identical(tmp_path, kind):
         assert torch.isfinite(g0).all() and g0.abs().max() > 0
     assert torch.equal(r0["flat"], r1["flat"])          # three identical AdamW updates on the broadcast parameters
     assert r0["loss"] != r1["loss"]                     # ... although the ranks saw different data
+
+
+def test_ctunet_gradients_become_ready_in_bucket_order():
+    """Bucket layout = gradient_ready_order; what matters for overlap is that the real backward agrees with it: the
+    parameter-heavy ViT trunk must be done well before the end (CTUNet.forward builds the ResNet branch first for exactly
+    this), the last gradients to appear must be the small stem of the convnet, and buckets must complete roughly in
+    order."""
+    import hybrid_ctunet_amd as H
+    from oracle.ctunet_oracle import synthetic_batch
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = H.build_model("ctunet", model_depth=50).to(dev)
+    order = H.gradient_ready_order(model)
+    flat = H.FlatParams(order)
+    dp = H.DataParallel(model, flat=flat, bucket_mb=32.0)
+    fired = []
+    flat.listeners.append(lambda i: fired.append(i))
+    names = {id(p): n for n, p in model.named_parameters()}
+    x, y = synthetic_batch(1, seed=1000)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = H.ctunet_loss(model(x.to(dev)), y.to(dev))
+    loss.backward()
+    dp.finish()
+    seen, seq = set(), []
+    for i in fired:                       # first report of every parameter
+        if i not in seen:
+            seen.add(i)
+            seq.append(i)
+    pos = {i: k for k, i in enumerate(seq)}
+    n = len(seq)
+    vit = [pos[i] for i, p in enumerate(flat.params) if i in pos and names[id(p)].startswith("vit.transformer")]
+    conv = [pos[i] for i, p in enumerate(flat.params) if i in pos and names[id(p)].startswith("convnet.")]
+    assert vit and conv and max(vit) < min(conv)                       # the whole convnet backward still follows the trunk
+    assert names[id(flat.params[seq[-1]])].startswith("convnet.")      # the tail is the ResNet's shallow end
+    # buckets complete (last member reported) in nearly increasing order: count inversions between neighbours
+    done = []
+    for begin, end, members in dp.buckets:
+        ks = [pos[i] for i in members if i in pos]
+        if ks:
+            done.append(max(ks))
+    inv = sum(1 for a, b in zip(done, done[1:]) if b < a)
+    assert inv <= max(1, len(done) // 5), (inv, done)

@@ -103,7 +103,12 @@ def test_gradient_ready_order_covers_all_parameters():
     assert len(order) == 412 and len({id(p) for p in order}) == 412
     names = {id(p): n for n, p in m.named_parameters()}
     first, last = names[id(order[0])], names[id(order[-1])]
-    assert first.startswith("res_out_24x24") and last.startswith("vit.")
+    assert first.startswith("res_out_24x24") and last.startswith("convnet.")   # the stem: last and smallest
+    # the parameter-heavy ViT trunk sits in the middle of the order (CTUNet.forward builds the ResNet first), so its
+    # all-reduce overlaps the convnet's backward
+    pos = [i for i, p in enumerate(order) if names[id(p)].startswith("vit.transformer")]
+    conv = [i for i, p in enumerate(order) if names[id(p)].startswith("convnet.")]
+    assert max(pos) < min(conv)
 
 
 class _Toy(nn.Module):
