@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
       // (whole tiles only: a tail tile may skip a store, and counting one that was never issued would end the wait early;
       //  pre_out doubles the stores - counting fewer than issued only waits longer)
-      after_epi = p.splitk <= 1 && cur.m0 + BM <= p.M && cur.n0 + BN <= p.N;
+      after_epi = p.splitk <= 1 && cur.m0 + BM <= p.M && cur.n0 + BN <= p.N && !(p.debug & 1);
       tm += tm_step;
       if (tm >= p.tiles_m) break;
       cur.m0 = tm * BM;
