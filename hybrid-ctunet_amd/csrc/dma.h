@@ -2,6 +2,14 @@
 #pragma once
 #include "common.h"
 
+// cache-policy modifiers of the DMA loads (experiments: " nt", " sc1", ...): per translation unit, before this include
+#ifndef CTU_DMA_MOD
+#define CTU_DMA_MOD ""        // dma16 (gathers: halo voxels, GEMM tails)
+#endif
+#ifndef CTU_DMA_GROUP_MOD
+#define CTU_DMA_GROUP_MOD ""  // grouped issues (weight stages, GEMM tiles)
+#endif
+
 static __device__ __attribute__((aligned(16))) uint32_t g_zero16[4];  // 16 zero bytes: DMA source of padding slots
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -15,7 +23,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_
   const unsigned dst =
       __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base);
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" CTU_DMA_MOD "\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(gsrc), "s"(dst)
                : "memory");
@@ -58,16 +66,16 @@ __device__ __forceinline__ void dma16_group(int n, const void* sbase, unsigned v
                         (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
   unsigned keep;
   if (n == 3)
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\ts_mov_b32 m0, %0"
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5" CTU_DMA_GROUP_MOD "\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5" CTU_DMA_GROUP_MOD "\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5" CTU_DMA_GROUP_MOD "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(v0), "v"(v1), "v"(v2), "s"(dst), "s"(base) : "memory", "scc");
   else if (n == 2)
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\ts_mov_b32 m0, %0"
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4" CTU_DMA_GROUP_MOD "\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4" CTU_DMA_GROUP_MOD "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(v0), "v"(v1), "s"(dst), "s"(base) : "memory", "scc");
   else if (n == 1)
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3" CTU_DMA_GROUP_MOD "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(v0), "s"(dst), "s"(base) : "memory");
 }
 
@@ -82,17 +90,17 @@ __device__ __forceinline__ void dma16_groupN(const void* sbase, const unsigned (
                         (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
   unsigned keep;
   if constexpr (N == 4)
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6\n\t"
-                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
-                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6\n\t"
-                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %6\n\ts_mov_b32 m0, %0"
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6" CTU_DMA_GROUP_MOD "\n\t"
+                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6" CTU_DMA_GROUP_MOD "\n\t"
+                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6" CTU_DMA_GROUP_MOD "\n\t"
+                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %6" CTU_DMA_GROUP_MOD "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(dst), "s"(base), "n"(STRIDE)
                  : "memory", "scc");
   else if constexpr (N == 2)
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
-                 "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\ts_mov_b32 m0, %0"
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4" CTU_DMA_GROUP_MOD "\n\t"
+                 "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4" CTU_DMA_GROUP_MOD "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(v[0]), "v"(v[1]), "s"(dst), "s"(base), "n"(STRIDE) : "memory", "scc");
   else
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3" CTU_DMA_GROUP_MOD "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(v[0]), "s"(dst), "s"(base) : "memory");
 }
