@@ -48,6 +48,7 @@ _SIGS = {
     "ctu_in_finalize": [_i32, _i64, _i32, _vp, _vp, _vp],
     "ctu_conv3_halo_wgrad": [_i32, _vp, _vp, _vp, _vp] + [_i32] * 7 + [_vp],
     "ctu_pack_frag": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp],
+    "ctu_pack_frag_batched": [_vp, _i32, _i64, _vp],
     "ctu_im2col_cin1": [_vp, _vp, C.POINTER(Geom), _i32, _vp],
     "ctu_conv_cin1_fwd": [_i32, _vp, _vp, _vp, C.POINTER(Geom), _vp],
     "ctu_conv_cin1_wgrad": [_i32, _vp, _vp, _vp, C.POINTER(Geom), _vp],

@@ -893,3 +893,39 @@ extern "C" int ctu_pack_frag(const float* src, void* dst, ctu_dtype dst_dtype, i
   else { ctu_set_error("pack_frag: bad dtype"); return CTU_ERR_ARG; }
   return ctu_check_launch("pack_frag");
 }
+
+// Many panels in ONE launch (94 single launches of ~7 us each per training step otherwise - pure launch latency): job table
+// in device memory, blockIdx.y = job.
+__global__ __launch_bounds__(256) void pack_frag_batched_kernel(const ctu_pack_job* __restrict__ jobs, const int count) {
+  // flat grid: job j owns blocks [block0_j, block0_{j+1}) (sized by its element count: the panels span 27 k .. 7 M elements)
+  int lo = 0, hi = count - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block0 <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const ctu_pack_job jb = jobs[lo];
+  const float* __restrict__ src = jb.src;
+  const int64_t nblk = (lo + 1 < count ? jobs[lo + 1].block0 : (int64_t)gridDim.x) - jb.block0;
+  for (int64_t i = ((int64_t)blockIdx.x - jb.block0) * 256 + threadIdx.x; i < jb.total; i += nblk * 256) {
+    const int j = (int)(i & 7);
+    const int lane = (int)((i >> 3) & 63);
+    int64_t q = i >> 9;
+    const int nt = (int)(q % jb.ntn); q /= jb.ntn;
+    const int kk = (int)(q & 1); q >>= 1;
+    const int tap = (int)(q % jb.taps);
+    const int chunk = (int)(q / jb.taps);
+    const int n = nt * 32 + (lane & 31);
+    const int c = chunk * 32 + kk * 16 + 8 * (lane >> 5) + j;
+    const int ts = jb.flip ? jb.taps - 1 - tap : tap;
+    float v = 0.f;
+    if (n < jb.N && c < jb.K) v = src[(int64_t)n * jb.sn + (int64_t)c * jb.sc + (int64_t)ts * jb.st];
+    if (jb.dst_dtype == CTU_BF16) reinterpret_cast<bf16*>(jb.dst)[i] = (bf16)v;
+    else reinterpret_cast<float*>(jb.dst)[i] = v;
+  }
+}
+
+extern "C" int ctu_pack_frag_batched(const ctu_pack_job* jobs_dev, int32_t count, int64_t total_blocks, ctu_stream_t stream) {
+  CTU_REQUIRE(jobs_dev && count > 0 && total_blocks >= count && total_blocks < (1ll << 31), "pack_frag_batched: bad args");
+  hipLaunchKernelGGL(pack_frag_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, count);
+  return ctu_check_launch("pack_frag_batched");
+}

@@ -388,7 +388,7 @@ class ConvFn(torch.autograd.Function):
         dout = tuple((n + 2 * p - kk) // s + 1 for n, p, kk, s in zip((D, H, W), padding, k, stride))
         out = torch.empty((B, *dout, N), dtype=x1.dtype, device=x1.device)
         if _halo_ok(k, stride, padding) and C1 % 32 == 0 and C2 % 32 == 0:
-            wfr = _packed(weight, "conv_hf", x1.dtype, lambda: _pack_frag(weight, N, K, taps, K * taps, taps, 1, 0, x1.dtype))
+            wfr = _packed_frag(weight, "conv_hf", x1.dtype, N, K, taps, K * taps, taps, 1, 0)
             acc = None
             if FUSE_IN_STATS and x1.dtype == torch.bfloat16 and B * D * H * W * max(C1, C2) < (1 << 31):
                 # InstanceNorm statistics of the output from the conv epilogue (consumed by instance_norm, if it follows)
@@ -427,8 +427,7 @@ class ConvFn(torch.autograd.Function):
             g2 = torch.empty_like(x2) if x2 is not None else None
             if _halo_ok(k, stride, padding) and N % 32 == 0 and (x2 is None or C1 % 32 == 0):
                 # dX = conv(dY, W flipped, in/out channels swapped): W'(n'=cin, c'=cout, t') = W[cout][cin][26 - t']
-                wfr = _packed(weight, "conv_hd", x1.dtype,
-                              lambda: _pack_frag(weight, K, N, taps, taps, K * taps, 1, 1, x1.dtype))
+                wfr = _packed_frag(weight, "conv_hd", x1.dtype, K, N, taps, taps, K * taps, 1, 1)
                 ws = _tn_workspace(x1.device)
                 extra = None
                 if ctx.grad_stash and x2 is None and x1.dtype == torch.bfloat16 and B * D * H * W * max(N, K) < (1 << 31):
@@ -490,6 +489,93 @@ USE_HALO_CONV = True  # tests flip this to run the generic implicit GEMM on the 
 
 def _halo_ok(k, stride, padding) -> bool:
     return USE_HALO_CONV and tuple(k) == (3, 3, 3) and tuple(stride) == (1, 1, 1) and tuple(padding) == (1, 1, 1)
+
+
+# Batched fragment packing.  Every 3x3x3 conv repacks its weights twice per step (forward panel, flipped / transposed
+# data-gradient panel): 94 launches of ~7 us for CTUNet, all latency.  The first step registers each (parameter, kind)
+# job as it packs it singly; from then on the first stale lookup of a step repacks ALL registered panels with one launch
+# (job table in device memory, two alternating output buffers so that a graph built before the update keeps its panels
+# alive one more round).
+BATCH_PACK = not os.environ.get("CTU_NO_BATCH_PACK")
+_frag_jobs = {}      # (id(param), kind, dtype) -> [weakref(param), (N, K, taps, sn, sc, st, flip), numel]
+_frag_state = {"side": 0, "tables": [None, None]}  # per side: (signature, job keys, table tensor, buffer, views)
+
+
+def _frag_numel(N, K, taps):
+    return (K // 32) * taps * 2 * ((N + 31) // 32) * 512
+
+
+def _packed_frag(param, kind, dtype, N, K, taps, sn, sc, st, flip):
+    """Fragment panel of a conv weight (cached per parameter like _packed; batched repacking, see above)."""
+    single = lambda: _pack_frag(param, N, K, taps, sn, sc, st, flip, dtype)  # noqa: E731
+    if not (BATCH_PACK and isinstance(param, torch.nn.Parameter) and param.is_contiguous() and param.dtype == torch.float32):
+        return _packed(param, kind, dtype, single)
+    key = (id(param), kind, dtype)
+    job = _frag_jobs.get(key)
+    if job is None or job[0]() is not param or job[1] != (N, K, taps, sn, sc, st, flip):
+        pid = id(param)
+        _frag_jobs[key] = [weakref.ref(param, lambda _r, key=key: _frag_jobs.pop(key, None)), (N, K, taps, sn, sc, st, flip),
+                           _frag_numel(N, K, taps)]
+        return _packed(param, kind, dtype, single)       # first sight: pack it alone
+    ent = _pack_cache.get(id(param))
+    ver = (param._version, _weights_epoch, param.data_ptr(), tuple(param.shape))
+    hit = ent[1].get((kind, dtype)) if ent is not None and ent[0]() is param else None
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    _repack_all(param.device)
+    ent = _pack_cache.get(id(param))
+    hit = ent[1].get((kind, dtype)) if ent is not None and ent[0]() is param else None
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    return _packed(param, kind, dtype, single)           # (not covered by the batch after all)
+
+
+def _repack_all(device):
+    """One launch for every registered panel of live parameters on `device`; results go into the _packed cache."""
+    live = []
+    for key, job in list(_frag_jobs.items()):
+        prm = job[0]()
+        if prm is None or prm.device != device or not prm.is_contiguous():
+            continue
+        live.append((key, prm, job))
+    if not live:
+        return
+    st = _frag_state
+    side = st["side"] = 1 - st["side"]
+    sig = tuple((key, prm.data_ptr()) for key, prm, _ in live)
+    tab = st["tables"][side]
+    if tab is None or tab[0] != sig:
+        import numpy as np
+        offs, total_bytes = [], 0
+        for key, prm, job in live:
+            offs.append(total_bytes)
+            total_bytes += (job[2] * (2 if key[2] == torch.bfloat16 else 4) + 255) // 256 * 256
+        buf = torch.empty(total_bytes, dtype=torch.uint8, device=device)
+        rows = np.zeros((len(live), 10), dtype=np.int64)    # 80-byte ctu_pack_job records
+        views = []
+        nblocks = 0
+        for r, ((key, prm, job), off) in enumerate(zip(live, offs)):
+            N, K, taps, sn, sc, stt, flip = job[1]
+            nbytes = job[2] * (2 if key[2] == torch.bfloat16 else 4)
+            view = buf[off:off + nbytes].view(key[2])
+            views.append(view)
+            rows[r, 0] = prm.data_ptr()
+            rows[r, 1] = view.data_ptr()
+            rows[r, 2:7] = (sn, sc, stt, job[2], nblocks)
+            nblocks += max(1, min(2048, (job[2] + 2047) // 2048))   # ~8 elements per thread, at most 2048 workgroups a job
+            i32 = np.array([N, K, taps, flip, (N + 31) // 32, dcode(key[2])], dtype=np.int32)
+            rows[r, 7:10] = i32.view(np.int64)
+        table = torch.from_numpy(rows.view(np.uint8).reshape(-1)).to(device)
+        tab = st["tables"][side] = (sig, [k for k, _, _ in live], table, buf, views, nblocks)
+    call("ctu_pack_frag_batched", ptr(tab[2]), len(live), tab[5], stream())
+    for (key, prm, job), view in zip(live, tab[4]):
+        ver = (prm._version, _weights_epoch, prm.data_ptr(), tuple(prm.shape))
+        ent = _pack_cache.get(id(prm))
+        if ent is None or ent[0]() is not prm:
+            pid = id(prm)
+            ent = (weakref.ref(prm, lambda _r, pid=pid: _pack_cache.pop(pid, None)), {})
+            _pack_cache[pid] = ent
+        ent[1][(key[1], key[2])] = (ver, view)
 
 
 def _pack_frag(weight, N, K, taps, sn, sc, st, flip, dtype):

@@ -150,6 +150,16 @@ int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void* x1, const 
  * dst[K/32][taps][2][ceil(N/32)][64 lanes][8] (zero padded), optionally with the tap order reversed (flip = 1). */
 int ctu_pack_frag(const float* src, void* dst, ctu_dtype dst_dtype, int32_t N, int32_t K, int32_t taps, int64_t sn,
                   int64_t sc, int64_t st, int32_t flip, ctu_stream_t stream);
+/* The same for many panels in one launch: `jobs_dev` is a DEVICE array of `count` jobs (fields as the arguments of
+ * ctu_pack_frag; ntn = ceil(N / 32), total = (K / 32) * taps * 2 * ntn * 512 elements of dst).  Job j owns the workgroups
+ * [block0_j, block0_{j+1}) of a flat grid of `total_blocks` (block0 ascending, block0_0 = 0). */
+typedef struct ctu_pack_job {
+  const float* src;
+  void* dst;
+  int64_t sn, sc, st, total, block0;
+  int32_t N, K, taps, flip, ntn, dst_dtype;
+} ctu_pack_job;
+int ctu_pack_frag_batched(const ctu_pack_job* jobs_dev, int32_t count, int64_t total_blocks, ctu_stream_t stream);
 
 /* Strided 3-index permute + cast: dst[i0*d0 + i1*d1 + i2*d2] = (dst_dtype) src[i0*s0 + i1*s1 + i2*s2].
  * src is fp32 (master weights / packed fp32 gradients).  Used to pack weights into [taps][N][K] panels and
