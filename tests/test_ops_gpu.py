@@ -546,3 +546,42 @@ def test_fused_adamw_matches_torch(ops):
         ropt.step()
         for p, r in zip(ps, ref):
             assert torch.allclose(p, r, rtol=1e-5, atol=1e-6), step
+
+
+def test_batched_fragment_packing_equals_single(ops):
+    """From the second sight of a conv weight on, all registered 3x3x3 panels (forward and data-gradient form) are repacked
+    by ONE launch per weight update; outputs and gradients must be bit-identical to the one-launch-per-panel path."""
+    torch.manual_seed(0)
+    dtype = torch.bfloat16
+    shapes = [(64, 32), (32, 96), (128, 64)]           # (N, C): different panel sizes in one batch
+    ws = [torch.nn.Parameter((torch.randn(n, c, 3, 3, 3) / math.sqrt(27 * c)).cuda()) for n, c in shapes]
+    xs = [torch.randn(1, 8, 8, 8, c, device="cuda").to(dtype).requires_grad_(True) for _, c in shapes]
+
+    def run(batched):
+        ops.BATCH_PACK = batched
+        outs = []
+        for rnd_ in range(3):                          # round 0 registers, rounds 1-2 take the batched path
+            with torch.no_grad():
+                for w in ws:
+                    w.mul_(1.0 + 0.01 * (rnd_ + 1))    # a weight update the version counter sees
+            ops.bump_weights_epoch()                   # ... and one it does not (fused AdamW)
+            for x in xs:
+                x.grad = None
+            ys = [ops.conv3d(x, w, 1, 1) for x, w in zip(xs, ws)]
+            for y in ys:
+                y.float().square().mean().backward()
+            outs.append([y.detach().clone() for y in ys] + [x.grad.clone() for x in xs])
+        return outs
+
+    try:
+        ref_w = [w.detach().clone() for w in ws]
+        a = run(False)
+        with torch.no_grad():
+            for w, r in zip(ws, ref_w):
+                w.copy_(r)
+        b = run(True)
+    finally:
+        ops.BATCH_PACK = True
+    for ra, rb in zip(a, b):
+        for ta, tb in zip(ra, rb):
+            assert torch.equal(ta, tb)
