@@ -513,7 +513,6 @@ def _packed_frag(param, kind, dtype, N, K, taps, sn, sc, st, flip):
     key = (id(param), kind, dtype)
     job = _frag_jobs.get(key)
     if job is None or job[0]() is not param or job[1] != (N, K, taps, sn, sc, st, flip):
-        pid = id(param)
         _frag_jobs[key] = [weakref.ref(param, lambda _r, key=key: _frag_jobs.pop(key, None)), (N, K, taps, sn, sc, st, flip),
                            _frag_numel(N, K, taps)]
         return _packed(param, kind, dtype, single)       # first sight: pack it alone
