@@ -1,4 +1,5 @@
-"""Repeat the InstanceNorm-sum variant of gemm_nt_stream 150 times per shape against the general kernel: outputs must be\nbit-equal every time (a rare race would show as a sporadic mismatch), the sums equal to fp32 summation order."""
+"""Repeat the InstanceNorm-sum variant of gemm_nt_stream 150 times per shape against the general kernel: outputs must be
+bit-equal every time (a rare race would show as a sporadic mismatch), the sums equal to fp32 summation order."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
