@@ -73,8 +73,13 @@ template <int IPW, int MAXA, int EXTRA = 0> __device__ __forceinline__ void wait
 // 1x1x1 conv reads the forward weight [N_fwd][K_fwd] as is, no transposed copy.  Its B tile is staged as 32-column
 // panels [panel][64 k rows][32 n] (64-B rows, plain DMA) and read transposed, exactly like the TN kernel's operands.
 // BK = 32 serves K % 64 == 32 (the 32-channel layers): 64-B LDS rows, four to a bank row, slot ^ ((row >> 2) & 3).
-template <int BM, int BN, int R, bool BT, int BK = 64>
-__global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) void gemm_nt_dma_kernel(const GemmNtArgs p) {
+// KG = 2 (the 864-token trunk, 64 x 64 tiles, one workgroup per CU): EIGHT waves, two k groups of four.  Both groups work
+// on every stage - group g takes the k steps [g BK/32, (g + 1) BK/32) of it - so each SIMD holds two waves whose
+// ds_read -> MFMA chains interleave (with one wave per SIMD a 64 x 64 tile is a chain of exposed LDS latencies: 2.2 k
+// cycles per 128-deep stage for 256 cycles of MFMA); at the end of a tile group 1 hands its accumulators to group 0
+// through LDS.  No split-K atomics, no second pass.
+template <int BM, int BN, int R, bool BT, int BK = 64, int KG = 1>
+__global__ __launch_bounds__(256 * KG, (KG == 2 || R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) void gemm_nt_dma_kernel(const GemmNtArgs p) {
   static_assert(BK == 64 || BK == 128 || (BK == 32 && !BT), "stage depth");
   constexpr int ROWB = BK * 2;         // bytes of a tile row in LDS
   constexpr int SPR = BK / 8;          // 16-B slots per row
@@ -83,19 +88,23 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int WM = BM / 2, WN = BN / 2;  // wave tile: WM rows x WN columns (waves 2 x 2)
   constexpr int MI = WM / 32, NJ = WN / 32;
-  constexpr int APW = BM / RPI / 4;  // DMA instructions (1 KiB = RPI rows each) per wave and stage: A ...
-  constexpr int BPW = BN / RPI / 4;  // ... and B
+  constexpr int NW = 4 * KG;              // waves
+  constexpr int APW = BM / RPI / NW;  // DMA instructions (1 KiB = RPI rows each) per wave and stage: A ...
+  constexpr int BPW = BN / RPI / NW;  // ... and B
+  static_assert(APW >= 1 && BPW >= 1 && (KG == 1 || (BK / 16) % 2 == 0), "tile too small for the wave count");
   constexpr int EPI_LD = 32 + 4;
   constexpr int EPI_BYTES = 4 * 16 * EPI_LD * 4;
   constexpr int IPW = APW + BPW;   // DMA instructions per wave and stage
   static_assert((R - 2) * IPW + 8 <= 63, "vmcnt is a 6-bit count");
   constexpr int RED_BYTES = 4 * WN * 2 * 4;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[R * STAGE + EPI_BYTES + RED_BYTES];
+  constexpr int KRED_BYTES = KG == 2 ? 4 * 64 * MI * NJ * 16 * 4 : 0;  // group 1's accumulators on their way to group 0
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[R * STAGE + EPI_BYTES + RED_BYTES + KRED_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int kg = KG == 2 ? wave >> 2 : 0, w4 = wave & 3;  // k group, wave inside the group
+  const int wm = w4 >> 1, wn = w4 & 1;
   const int vid = xcd_remap(blockIdx.x, gridDim.x);
   // source-side bank swizzle of a tile row's 16-B slots (conflict-free ds_read_b128 of 32-row fragments)
   auto swz = [](int row) { return BK == 128 ? row & 15 : BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; };
@@ -204,8 +213,8 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
       const float s1 = rs1[j] + __shfl_xor(rs1[j], 32, 64);
       const float s2 = rs2[j] + __shfl_xor(rs2[j], 32, 64);
       if (h == 0) {
-        red[(wave * WN + j * 32 + r) * 2] = s1;
-        red[(wave * WN + j * 32 + r) * 2 + 1] = s2;
+        red[(w4 * WN + j * 32 + r) * 2] = s1;
+        red[(w4 * WN + j * 32 + r) * 2 + 1] = s2;
       }
       rs1[j] = 0.f; rs2[j] = 0.f;
     }
@@ -254,7 +263,8 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
 
     const unsigned char* sa = smem + st * STAGE;
 #pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
+    for (int k2 = 0; k2 < BK / 16 / KG; ++k2) {
+      const int kk = kg * (BK / 16 / KG) + k2;
       bf16x8 fa[MI], fb[NJ];
 #pragma unroll
       for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + (aoff[i] ^ (kk << 5)));
@@ -270,7 +280,29 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
     }
 
     if (last) {
-      if (p.in_acc) {
+      if constexpr (KG == 2) {
+        // lane-contiguous fp32 dump (conflict-free), one barrier; group 1 then goes straight to the next tile, and cannot
+        // overwrite the buffer before group 0 has read it: its next dump sits behind the loop-top barriers of a whole tile
+        float* kred = reinterpret_cast<float*>(smem + R * STAGE + EPI_BYTES + RED_BYTES) + w4 * (64 * MI * NJ * 16);
+        if (kg == 1) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) kred[((i * NJ + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kg == 0) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) acc[i][j][e] += kred[((i * NJ + j) * 16 + e) * 64 + lane];
+        }
+      }
+      if (KG == 1 && p.in_acc) {
         // InstanceNorm statistics of the output (the 1x1x1 convs of the ResNet bottlenecks feed an InstanceNorm): column
         // sums of the fp32 accumulators, kept in registers ACROSS the tiles of this persistent workgroup while they
         // belong to the same (batch item, n tile) - with gridDim a multiple of tiles_n that is all of them but one
@@ -286,6 +318,7 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) { const float v = acc[i][j][e]; rs1[j] += v; rs2[j] += v * v; }
       }
+      if (kg == 0) {  // (KG == 2: group 1 has handed its sums over and goes on to the next tile)
       // epilogue through a wave-private fp32 patch of PR rows x the wave's WN columns (outside the DMA ring: the next
       // tile is already in flight): every store instruction then writes whole rows of the wave's column range
       // (128 B for WN = 64) instead of 64-B halves of a line.  The residual vectors of all MI NR patches are requested
@@ -327,7 +360,7 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
           for (int e = 0; e < 8; ++e) bv[e] = p.ep.bias[n + e];
         }
       }
-      float* patch = reinterpret_cast<float*>(smem + R * STAGE) + wave * (EPI_BYTES / 16);
+      float* patch = reinterpret_cast<float*>(smem + R * STAGE) + w4 * (EPI_BYTES / 16);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -372,6 +405,7 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
           }
           __builtin_amdgcn_wave_barrier();
         }
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -380,7 +414,7 @@ __global__ __launch_bounds__(256, (R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) 
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
       // (whole tiles only: a tail tile may skip a store, and counting one that was never issued would end the wait early;
       //  pre_out doubles the stores - counting fewer than issued only waits longer)
-      after_epi = p.splitk <= 1 && cur.m0 + BM <= p.M && cur.n0 + BN <= p.N && !(p.debug & 1);
+      after_epi = kg == 0 && p.splitk <= 1 && cur.m0 + BM <= p.M && cur.n0 + BN <= p.N && !(p.debug & 1);
       tm += tm_step;
       if (tm >= p.tiles_m) break;
       cur.m0 = tm * BM;
@@ -705,6 +739,10 @@ int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {
     if (p.w_kn) return -1;
     if (BN == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 64, 3, false, 32>), g, b, 0, stream, p);
     else hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128, 3, false, 32>), g, b, 0, stream, p);
+  } else if (bk128 && !p.in_acc && p.splitk <= 1 && !getenv("CTU_NT_NO_KG2")) {
+    const dim3 b8(512);  // eight waves: two k groups per tile (see the kernel)
+    if (p.w_kn) hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 64, 3, true, 128, 2>), g, b8, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 64, 3, false, 128, 2>), g, b8, 0, stream, p);
   } else if (bk128) {
     if (p.w_kn) hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 64, 3, true, 128>), g, b, 0, stream, p);
     else hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 64, 3, false, 128>), g, b, 0, stream, p);
