@@ -147,11 +147,20 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # rehearsal switches (one-GPU boxes): CTU_BENCH_BACKEND=gloo CTU_BENCH_ONE_GPU=1 run all ranks on cuda:0 and move the
+    # buckets with gloo - the same control flow (barriers, instrumented steps, max-over-ranks timing) without RCCL
+    one_gpu = bool(os.environ.get("CTU_BENCH_ONE_GPU"))
+    backend = os.environ.get("CTU_BENCH_BACKEND", "nccl")
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import hybrid_ctunet_amd as H
     from hybrid_ctunet_amd import _lib
