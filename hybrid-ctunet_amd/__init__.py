@@ -13,10 +13,11 @@ from .train import (DataParallel, FlatParams, FusedAdamW, LOSSES, ctunet_loss, c
                     gradient_ready_order, tunet_loss)
 from .inference import dice_per_organ, hybrid_complement, sliding_window_inference  # noqa: F401
 from .checkpoint import load_checkpoint, save_checkpoint  # noqa: F401
+from .synthetic import synthetic_batch  # noqa: F401
 
 __all__ = ["CTUNet", "CUNet", "TUNet", "DataParallel", "FlatParams", "FusedAdamW", "LOSSES", "ctunet_loss",
            "cunet_loss", "tunet_loss", "dice_ce_loss", "gradient_ready_order", "sliding_window_inference",
-           "hybrid_complement", "dice_per_organ", "load_checkpoint", "save_checkpoint"]
+           "hybrid_complement", "dice_per_organ", "load_checkpoint", "save_checkpoint", "synthetic_batch"]
 
 
 def build_model(name: str, model_depth: int = 101, **kw):

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libctunet_hip.so")
 SOURCES = ["igemm.hip", "gemm_dma.hip", "conv3_halo.hip", "norm_elementwise.hip", "attention.hip", "attention_mfma.hip",
-           "loss_optim.hip", "infer.hip", "dropout.hip", "philox.h", "mma.h", "dma.h", "gemm_dma.h", "attn_common.h", "common.h"]
+           "loss_optim.hip", "infer.hip", "dropout.hip", "comm.hip", "philox.h", "mma.h", "dma.h", "gemm_dma.h", "attn_common.h", "common.h"]
 
 CTU_F32, CTU_BF16 = 0, 1
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -85,8 +85,12 @@ _SIGS = {
     "ctu_sw_normalize": [_vp, _vp, _i32, _i32, _i64, _vp],
     "ctu_hybrid_argmax": [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp],
     "ctu_set_option": [C.c_char_p, _i32],
+    "ctu_comm_unique_id": [C.c_char_p, _vp],
+    "ctu_comm_init": [C.c_char_p, _i32, _i32, _vp, C.POINTER(_vp)],
+    "ctu_comm_destroy": [_vp],
+    "ctu_allreduce_bucket": [_vp, _vp, _i64, _i32, _vp, _i64, _vp],
 }
-EXPORTED = sorted(list(_SIGS) + ["ctu_abi_version", "ctu_last_error"])
+EXPORTED = sorted(list(_SIGS) + ["ctu_abi_version", "ctu_last_error", "ctu_allreduce_scratch_bytes"])
 
 _lib = None
 
@@ -121,6 +125,8 @@ def lib():
             fn.argtypes = args
             fn.restype = C.c_int
         L.ctu_abi_version.restype = C.c_int
+        L.ctu_allreduce_scratch_bytes.argtypes = [_i32, _i64]
+        L.ctu_allreduce_scratch_bytes.restype = _i64
         L.ctu_last_error.restype = C.c_char_p
         if L.ctu_abi_version() != 2:
             raise RuntimeError("libctunet_hip.so ABI version mismatch")

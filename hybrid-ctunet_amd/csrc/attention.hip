@@ -17,10 +17,13 @@ static int g_generic_gemm = 0;  // "generic_gemm" = 1: plain GEMMs stay on the g
 int ctu_option_generic_gemm() { return g_generic_gemm; }
 static int g_nt_debug = 0;  // measurement hook of gemm_nt_dma (see gemm_dma.h)
 int ctu_option_nt_debug() { return g_nt_debug; }
+static int g_route = 0;  // A/B routing bits (see ctu_set_option "route" in ctunet_hip.h); read from memory, never getenv
+int ctu_option_route() { return g_route; }
 extern "C" int ctu_set_option(const char* name, int value) {
   if (name && !strcmp(name, "attn_valu")) { g_attn_force_valu = value; return CTU_OK; }
   if (name && !strcmp(name, "generic_gemm")) { g_generic_gemm = value; return CTU_OK; }
   if (name && !strcmp(name, "nt_debug")) { g_nt_debug = value; return CTU_OK; }
+  if (name && !strcmp(name, "route")) { g_route = value; return CTU_OK; }
   ctu_set_error("unknown option %s", name ? name : "(null)");
   return CTU_ERR_ARG;
 }

@@ -18,6 +18,11 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 void ctu_set_error(const char* fmt, ...);
 int ctu_check_launch(const char* what);
 int ctu_option_generic_gemm();  // test hook, see ctu_set_option
+int ctu_option_route();         // A/B routing bits, see ctu_set_option "route"
+#define CTU_ROUTE_NT_NO_STREAM 1    /* short-K layers back on the general NT kernel */
+#define CTU_ROUTE_NT_NO_BK128 2     /* no 128-deep stages for the 64x64 trunk tiles */
+#define CTU_ROUTE_NT_NO_KG2 4       /* no two-k-group 8-wave trunk tiles */
+#define CTU_ROUTE_HALO_KSPLIT_OLD 8 /* previous channel-split rule of the small-volume 3x3x3 convs */
 
 #define CTU_REQUIRE(cond, ...)      \
   do {                              \

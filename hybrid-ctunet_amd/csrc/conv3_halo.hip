@@ -491,7 +491,7 @@ template <> struct HaloDma<bf16> {
       // fill the 512 resident slots (2 workgroups per CU) ONCE: rounding up (540 workgroups for 512 -> 512 @ 12 x 12 x 24)
       // costs a second round for a handful of stragglers; down to one half chunk (9 stages) per workgroup if need be
       // (256 -> 256 @ 6 x 6 x 12: 72.6 -> 28.1 us)
-      const int slots = getenv("CTU_HALO_KSPLIT_OLD") ? 0 : 512;
+      const int slots = (ctu_option_route() & CTU_ROUTE_HALO_KSPLIT_OLD) ? 0 : 512;
       ksplit = slots ? slots / blocks : (512 + blocks - 1) / blocks;
       const int kmax = slots ? HCT : HCT / 2;
       if (ksplit > kmax) ksplit = kmax;

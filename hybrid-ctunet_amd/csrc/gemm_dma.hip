@@ -685,7 +685,7 @@ static bool stream_ok(const GemmNtArgs& p) {
   const ctu_epilogue& e = p.ep;
   return (p.K == 32 || p.K == 64 || p.K == 128) && p.a2 == nullptr && p.C1 == p.K && p.N % 128 == 0 && p.M % 128 == 0 &&
          p.M >= 128 * 256 && p.splitk <= 1 && !e.bias && e.act == 0 && !e.pre_out && !e.scatter && e.n_split <= 0 &&
-         (!p.in_acc || (p.in_rows % 128 == 0 && !e.residual)) && !getenv("CTU_NT_NO_STREAM");
+         (!p.in_acc || (p.in_rows % 128 == 0 && !e.residual)) && !(ctu_option_route() & CTU_ROUTE_NT_NO_STREAM);
 }
 static void launch_stream(const GemmNtArgs& p, hipStream_t stream) {
   const int cols = p.N / 128;
@@ -720,7 +720,7 @@ int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {
   // 64 x 64 tiles (the 864-token ViT trunk: a handful of MFMAs per 64-deep stage, the stage hand-over dominates) take
   // 128-deep stages when K allows: half the barriers and waits per tile, 8 MFMAs per wave between them
   const bool bk128 = !bk32 && BM == 64 && BN == 64 && p.K % 128 == 0 && p.K >= 512 && (!p.a2 || p.C1 % 128 == 0) &&
-                     !getenv("CTU_NT_NO_BK128");
+                     !(ctu_option_route() & CTU_ROUTE_NT_NO_BK128);
   p.ksteps = p.K / (bk32 ? 32 : bk128 ? 128 : 64);
   if (p.splitk > p.ksteps) p.splitk = p.ksteps;
   if (p.splitk < 1) p.splitk = 1;
@@ -739,7 +739,7 @@ int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {
     if (p.w_kn) return -1;
     if (BN == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 64, 3, false, 32>), g, b, 0, stream, p);
     else hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128, 3, false, 32>), g, b, 0, stream, p);
-  } else if (bk128 && !p.in_acc && p.splitk <= 1 && !getenv("CTU_NT_NO_KG2")) {
+  } else if (bk128 && !p.in_acc && p.splitk <= 1 && !(ctu_option_route() & CTU_ROUTE_NT_NO_KG2)) {
     const dim3 b8(512);  // eight waves: two k groups per tile (see the kernel)
     if (p.w_kn) hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 64, 3, true, 128, 2>), g, b8, 0, stream, p);
     else hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 64, 3, false, 128, 2>), g, b8, 0, stream, p);

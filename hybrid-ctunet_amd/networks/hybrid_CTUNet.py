@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from typing import Sequence, Tuple, Union
 
+import warnings
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -351,19 +353,34 @@ class _Base(nn.Module):
         self.precision = precision
         return self
 
+    _warned_fp16 = False
+
     def _dtype(self):
+        """Compute dtype of this forward.  Under the reference's default AMP - `torch.cuda.amp.autocast()` = float16 with
+        a GradScaler (trainer_CTUNet.py:21,90,106-112) - the kernels compute in bfloat16 (same operand width, fp32
+        accumulation, fp32 exponent range: a scaled loss cannot overflow) and the logits are handed back as float16,
+        the dtype the caller's loss expects; the GradScaler then simply never sees an inf."""
+        self._fp16_out = False
         if self.precision == "bf16":
             return torch.bfloat16
         if self.precision == "fp32":
             return torch.float32
         if torch.is_autocast_enabled():
             dt = torch.get_autocast_gpu_dtype()
-            if dt == torch.bfloat16:
-                return torch.bfloat16
-            raise NotImplementedError(
-                "autocast(float16) is not supported by the MI355X kernels: use torch.autocast('cuda', dtype=torch.bfloat16) "
-                "(no GradScaler needed) or model.set_precision('bf16')")
+            if dt == torch.float16:
+                if not _Base._warned_fp16:
+                    _Base._warned_fp16 = True
+                    warnings.warn("autocast(float16): the MI355X kernels compute in bfloat16 and return float16 logits; "
+                                  "torch.autocast('cuda', dtype=torch.bfloat16) avoids the final cast and needs no GradScaler")
+                self._fp16_out = True
+            return torch.bfloat16
         return torch.float32
+
+    def _outputs(self, outs):
+        """Logits as the caller's autocast dtype expects them (float16 under the reference's default AMP)."""
+        if not self._fp16_out:
+            return outs
+        return tuple(self._outputs(o) if isinstance(o, tuple) else o.to(torch.float16) for o in outs)
 
     def _input(self, x_in):
         if x_in.dim() != 5 or x_in.shape[1] != 1:
@@ -463,7 +480,7 @@ class CTUNet(_VitBranch):
         res_logits = self.res_out(res_out)
         res_logits_48x48 = self.res_out_48x48(res_dec1)
         res_logits_24x24 = self.res_out_24x24(res_dec2)
-        return ((res_logits, res_logits_48x48, res_logits_24x24), (vit_logits, vit_96x96))
+        return self._outputs(((res_logits, res_logits_48x48, res_logits_24x24), (vit_logits, vit_96x96)))
 
 
 class CUNet(_Base):
@@ -490,7 +507,7 @@ class CUNet(_Base):
         res_dec2 = self.res_decoder2(res_dec3, res_enc2)
         res_dec1 = self.res_decoder1(res_dec2, res_enc1)
         res_out = self.res_decoder0(res_dec1)
-        return (self.res_out(res_out), self.res_out_48x48(res_dec1), self.res_out_24x24(res_dec2))
+        return self._outputs((self.res_out(res_out), self.res_out_48x48(res_dec1), self.res_out_24x24(res_dec2)))
 
 
 class TUNet(_VitBranch):
@@ -508,4 +525,4 @@ class TUNet(_VitBranch):
     def forward(self, x_in):
         x = self._input(x_in)
         _, vit_logits, vit_96x96 = self._vit_forward(x)
-        return (vit_logits, vit_96x96)
+        return self._outputs((vit_logits, vit_96x96))

@@ -101,12 +101,35 @@ def register_grad_sink(param: torch.Tensor, callback):
     _grad_sinks[param.data_ptr()] = (weakref.ref(param), callback)
 
 
+def unregister_grad_sink(param: torch.Tensor):
+    _grad_sinks.pop(param.data_ptr(), None)
+
+
 def clear_grad_sinks():
     _grad_sinks.clear()
+    _sink_uses.clear()
+
+
+# A parameter may be used by several ops of one graph (weight sharing).  Every forward that will accumulate into a sink
+# announces itself (sink_expect); the sink's callback - "this gradient is complete" - fires only when the last announced
+# use has accumulated.  Counts are per storage address and are cleared at the step boundary (reset_grad_sink_counts:
+# FlatParams.zero_grad / DataParallel.finish), so a forward whose backward never ran cannot poison the next step.
+_sink_uses = {}
+
+
+def sink_expect(param):
+    if param is not None and param.requires_grad and torch.is_grad_enabled() and param.data_ptr() in _grad_sinks:
+        k = param.data_ptr()
+        _sink_uses[k] = _sink_uses.get(k, 0) + 1
+
+
+def reset_grad_sink_counts():
+    _sink_uses.clear()
 
 
 def _direct_grad(param):
-    """param.grad if a sink is registered for this parameter and its .grad can be accumulated into in place."""
+    """param.grad if a sink is registered for this parameter and its .grad can be accumulated into in place; the second
+    value is the 'accumulated' notification, which reports the gradient complete once every counted use has run."""
     ent = _grad_sinks.get(param.data_ptr()) if param is not None else None
     if ent is None:
         return None, None
@@ -114,7 +137,16 @@ def _direct_grad(param):
     if p is None or p.grad is None or p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or \
             p.grad.shape != param.shape:
         return None, None
-    return p.grad, lambda: ent[1](p)
+
+    def done():
+        k = p.data_ptr()
+        left = _sink_uses.get(k, 1) - 1
+        if left > 0:
+            _sink_uses[k] = left
+            return
+        _sink_uses.pop(k, None)
+        ent[1](p)
+    return p.grad, done
 
 
 def permute3(src: torch.Tensor, dst: torch.Tensor, n, s, d, accumulate=False):
@@ -291,6 +323,8 @@ class LinearFn(torch.autograd.Function):
                 global _last_in_acc
                 _last_in_acc = acc
         ctx.save_for_backward(x, weight, pre, bias)
+        sink_expect(weight)
+        sink_expect(bias)
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         ctx.act = act
@@ -405,6 +439,8 @@ class ConvFn(torch.autograd.Function):
             sk = _conv_splitk(M, N, K, taps)
             _igemm_nt(x1, x2, wf, out, g, _epi(N, splitk=sk, splitk_ws=_splitk_workspace(x1.device, M * N) if sk > 1 else None))
         ctx.save_for_backward(x1, x2, weight)
+        if taps > 1:
+            sink_expect(weight)
         ctx.cfg = (stride, padding, k, dout)
         if getattr(ctx, "in_acc", None) is not None:
             global _last_in_acc
@@ -848,6 +884,8 @@ class LayerNormFn(torch.autograd.Function):
         mr = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
         call("ctu_layernorm_fwd", dcode(x.dtype), ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mr), rows, dim, stream())
         ctx.save_for_backward(x, gamma, mr, beta)
+        sink_expect(gamma)
+        sink_expect(beta)
         return y
 
     @staticmethod
@@ -947,7 +985,11 @@ def dropout_state() -> Tuple[int, int]:
     """(seed, offset of the next dropout call)."""
     global _drop_seed
     if _drop_seed is None:
-        _drop_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        # default: torch's seed, with the data-parallel rank mixed in - the reference seeds every rank alike
+        # (torch.manual_seed in main_worker) and still gets different masks per GPU from its per-device generators
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        _drop_seed = (int(torch.initial_seed()) ^ (rank * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
     return _drop_seed, _drop_offset
 
 

@@ -14,6 +14,7 @@ import torch.nn as nn
 from . import ops
 from ._lib import call, dcode, ptr, require_device, stream
 import ctypes as C
+import weakref
 
 # ---------------------------------------------------------------------------------------------------------------
 # DiceCE
@@ -138,6 +139,13 @@ class FlatParams:
         self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
+        for p in self.params:
+            # One owner per parameter: a second FlatParams would leave the first one's hooks and gradient sinks registered,
+            # and both would fold every gradient (2x, 3x, ... the true value).  Share the existing one instead
+            # (FlatParams.of(params), DataParallel(...).flat, FusedAdamW(..., flat=...)) or release() it first.
+            if getattr(p, "_ctu_flat", None) is not None and p._ctu_flat() is not None:
+                raise RuntimeError("parameter already belongs to a FlatParams: pass that object (`flat=`) instead of "
+                                   "building a second one, or call its release() first")
         dev = self.params[0].device
         self.offsets = []
         off = 0
@@ -157,11 +165,35 @@ class FlatParams:
         self.touched = [False] * len(self.params)
         self.listeners = []  # callables(i): "the gradient of parameter i is complete for this backward"
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+        me = weakref.ref(self)
+        for p in self.params:
+            p._ctu_flat = me
         if self.flat.is_cuda:
             # let weight-gradient kernels accumulate straight into the flat buffer (no zero-filled temporaries, no adds)
             for i, p in enumerate(self.params):
                 ops.register_grad_sink(p, self._make_sink(i))
         ops.bump_weights_epoch()
+
+    @staticmethod
+    def of(params: Iterable[nn.Parameter]) -> Optional["FlatParams"]:
+        """The FlatParams that already owns exactly these trainable parameters (any order), or None."""
+        ps = [p for p in params if p.requires_grad]
+        owners = {id(o): o for o in (getattr(p, "_ctu_flat", None) and p._ctu_flat() for p in ps) if o is not None}
+        if len(owners) != 1:
+            return None
+        owner = next(iter(owners.values()))
+        return owner if {id(p) for p in ps} == {id(p) for p in owner.params} else None
+
+    def release(self):
+        """Give the parameters up: hooks and gradient sinks are removed (the parameters keep their storage in the flat
+        buffers, which stay alive through them)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for p in self.params:
+            ops.unregister_grad_sink(p)
+            p._ctu_flat = None
+        self.listeners = []
 
     def _ready(self, i):
         self.touched[i] = True
@@ -173,12 +205,15 @@ class FlatParams:
 
     def _make_hook(self, i):
         def hook(p):
-            # autograd may have replaced .grad (first accumulation into a None grad): fold it back into the flat buffer
+            # .grad is not the flat view: the caller reset it (`param.grad = None`, trainer_CTUNet.py:88-89, or
+            # torch.optim's zero_grad()) and autograd installed a fresh tensor holding everything accumulated since that
+            # reset.  COPY it in (the slice still holds the previous step's gradient - adding would accumulate across
+            # steps) and re-point .grad at the slice, so later accumulations of this backward land in place.
             g = p.grad
             o = self.offsets[i]
             view = self.grad[o:o + p.numel()].view(p.shape)
             if g is not None and g.data_ptr() != view.data_ptr():
-                view.add_(g)
+                view.copy_(g)
                 p.grad = view
             self._ready(i)
         return hook
@@ -187,6 +222,7 @@ class FlatParams:
         """Equivalent of `param.grad = None` (trainer_CTUNet.py:88-89) without giving up the flat views."""
         self.grad.zero_()
         self.touched = [False] * len(self.params)
+        ops.reset_grad_sink_counts()
         for p, o in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
@@ -209,7 +245,10 @@ class FusedAdamW:
     SURVEY.md section 8a row D) are skipped exactly like torch skips `grad is None`."""
 
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, flat: Optional[FlatParams] = None):
-        self.flat = flat if flat is not None else FlatParams(params)
+        if flat is None:
+            params = list(params)
+            flat = FlatParams.of(params) or FlatParams(params)   # e.g. the one DataParallel(model) built
+        self.flat = flat
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.m = torch.zeros_like(self.flat.flat)
         self.v = torch.zeros_like(self.flat.flat)
@@ -290,13 +329,22 @@ class DataParallel(nn.Module):
     (trainer_CTUNet.py:309 unwraps it).  Works with any backend: "nccl" (= RCCL) on GPUs, "gloo" in CPU tests."""
 
     def __init__(self, module: nn.Module, flat: Optional[FlatParams] = None, bucket_mb: float = 32.0,
-                 process_group=None, ready_order: Optional[Sequence[nn.Parameter]] = None, broadcast: bool = True):
+                 process_group=None, ready_order: Optional[Sequence[nn.Parameter]] = None, broadcast: bool = True,
+                 payload: str = "fp32", comm=None):
         super().__init__()
+        if payload not in ("fp32", "bf16"):
+            raise ValueError("payload must be 'fp32' or 'bf16'")
         self.module = module
         self.pg = process_group
+        self.payload = payload
+        self._comm = comm   # comm.Communicator (RCCL through the C ABI) for the bf16 payload path
+        if payload == "bf16" and comm is None:
+            raise ValueError("payload='bf16' needs a comm.Communicator (hybrid_ctunet_amd.comm.Communicator.from_torch())")
         self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
         params = list(ready_order) if ready_order is not None else [p for p in module.parameters() if p.requires_grad]
-        self.flat = flat if flat is not None else FlatParams(params)
+        if flat is None:
+            flat = FlatParams.of(params) or FlatParams(params)
+        self.flat = flat
         f = self.flat
         # bucket boundaries on parameter boundaries
         target = int(bucket_mb * 1024 * 1024 / 4)
@@ -328,7 +376,10 @@ class DataParallel(nn.Module):
         return self.module(*a, **kw)
 
     def _on_ready(self, i):
-        if self._seen[i]:  # a parameter used twice in one graph reports twice; count it once
+        # One report per parameter and backward: autograd's AccumulateGrad node runs once however often the parameter is
+        # used (the engine sums the contributions first), and the direct gradient sinks report only after the LAST of the
+        # uses counted in forward (ops.sink_expect / sink_done).  A duplicate report is ignored all the same.
+        if self._seen[i]:
             return
         self._seen[i] = True
         b = self._bucket_of[i]
@@ -348,11 +399,25 @@ class DataParallel(nn.Module):
             ev.record(torch.cuda.current_stream())
             self._side.wait_event(ev)
             with torch.cuda.stream(self._side):
-                sl.mul_(1.0 / self.world)
-                dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg)
+                self._reduce_cuda(sl)
         else:
-            sl.mul_(1.0 / self.world)
+            sl.mul_(1.0 / self.world)   # gloo (CPU tests) has no AVG
             self._works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _reduce_cuda(self, sl):
+        """Mean of one bucket slice over the ranks, on the side stream.  payload "fp32": one RCCL all-reduce with the
+        average folded into the collective (ncclAvg: no scaling pass).  payload "bf16": the slice is rounded to bf16
+        once, every rank receives the other ranks' chunk of it (reduce-scatter as an all-to-all, one message per peer:
+        all 7 xGMI links at once), sums its chunk in fp32, and the bf16 means are all-gathered - half the bytes of the
+        fp32 ring, accumulation still fp32 (csrc/comm.hip via ctu_allreduce_bucket)."""
+        backend = dist.get_backend(self.pg)
+        if self.payload == "bf16" and self._comm is not None:
+            self._comm.allreduce_mean_bf16(sl)
+        elif backend == "nccl":
+            dist.all_reduce(sl, op=dist.ReduceOp.AVG, group=self.pg)
+        else:  # gloo moving device buffers (one-GPU rehearsals)
+            sl.mul_(1.0 / self.world)
+            dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg)
 
     def finish(self):
         """Call after backward, before the optimizer step."""
@@ -367,6 +432,7 @@ class DataParallel(nn.Module):
         self._pending = [len(mem) for _, _, mem in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._seen = [False] * len(self.flat.params)
+        ops.reset_grad_sink_counts()
 
 
 def gradient_ready_order(model: nn.Module) -> List[nn.Parameter]:

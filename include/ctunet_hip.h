@@ -38,7 +38,11 @@ int ctu_abi_version(void);
 const char* ctu_last_error(void);
 /* Test hooks (process-wide): "attn_valu" = 1 makes ctu_attn_fwd/_bwd use the VALU reference kernels even where the MFMA
  * kernels apply; "generic_gemm" = 1 keeps plain bf16 GEMMs on the generic implicit-GEMM kernels instead of the LDS-DMA
- * GEMM kernels - so both implementations can be checked against the oracle in one process. */
+ * GEMM kernels - so both implementations can be checked against the oracle in one process.  "route" = bit set of A/B
+ * routing switches for measurements (1: short-K layers on the general NT kernel instead of gemm_nt_stream, 2: no 128-deep
+ * stages, 4: no two-k-group trunk tiles, 8: previous channel-split rule of the small 3x3x3 convs); "nt_debug" = bits
+ * that switch a kernel's memory traffic off for timing.  Options are plain process-wide ints read per launch - no
+ * launch path calls getenv. */
 int ctu_set_option(const char* name, int32_t value);
 
 /* Geometry of an implicit GEMM over a channels-last volume.
@@ -318,6 +322,26 @@ int ctu_attn_bwd_dropout(ctu_dtype dtype, const void* qkv, const float* bias_tab
 /* Verification hook: the keep flags the attention kernels apply, keep[pairs = groups*heads][ntok][ntok], one byte each. */
 int ctu_attn_dropout_mask(uint8_t* keep, int32_t pairs, int32_t ntok, float p, uint64_t seed, uint64_t offset,
                           ctu_stream_t stream);
+
+/* ---- data-parallel gradient exchange over RCCL / xGMI ---------------------------------------------
+ * Replaces DistributedDataParallel's bucket all-reduce (main_CTUNet.py:116-118 init_process_group("nccl"), :187-189
+ * DDP(model, find_unused_parameters=True)).  One communicator per process (= per GPU), created once:
+ *   rank 0:      ctu_comm_unique_id(rccl_path, id)           id: 128 host bytes, sent to the other ranks by the caller
+ *   every rank:  ctu_comm_init(rccl_path, rank, world, id, &handle)   on the calling thread's current HIP device
+ * rccl_path names the RCCL shared object the process already uses (PyTorch ships its own librccl.so: pass that file so
+ * that one RCCL runtime serves both; a pure C++ host passes /opt/rocm/lib/librccl.so.1).  It is opened with dlopen - the
+ * library itself does not link RCCL.
+ * ctu_allreduce_bucket: buf[n] fp32 (device, 16-byte aligned) <- mean over the ranks, asynchronous on `stream` (the
+ * caller's side stream, fenced against the compute stream by events).  payload CTU_F32: one ncclAllReduce(ncclAvg).
+ * payload CTU_BF16: cast -> all-to-all (direct reduce-scatter: one message per peer, all 7 links at once) -> fp32 sum of
+ * the received chunks, x 1/world -> all-gather of the bf16 means -> expand; every rank ends with identical bf16-rounded
+ * means.  scratch: device memory of ctu_allreduce_scratch_bytes(world, n) bytes (unused for CTU_F32, may be NULL). */
+int ctu_comm_unique_id(const char* rccl_path, void* id128_host);
+int ctu_comm_init(const char* rccl_path, int32_t rank, int32_t world, const void* id128_host, void** handle);
+int ctu_comm_destroy(void* handle);
+int64_t ctu_allreduce_scratch_bytes(int32_t world, int64_t n);
+int ctu_allreduce_bucket(void* handle, float* buf, int64_t n, int32_t payload, void* scratch, int64_t scratch_bytes,
+                         ctu_stream_t stream);
 
 /* fp32 <-> dtype casts and fills */
 int ctu_cast(const void* src, ctu_dtype src_dtype, void* dst, ctu_dtype dst_dtype, int64_t n, ctu_stream_t stream);

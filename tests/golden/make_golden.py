@@ -13,6 +13,8 @@ What it does
       model_<model>.npz       whole-model 96^3 goldens: 4096 sampled logits per output + moments, per-sample loss,
                               B=2 loss and per-parameter gradient norms
       loss.npz                scipy.ndimage.zoom(order=0) index maps + DiceCE values on small random logits
+      model_<model>_bf16.npz  (--mode bf16) the reference under torch.autocast("cpu", bfloat16): the same samples
+      model_<model>_vox{32,64}.npz  (--mode f32|f64) whole class vectors of 2048 voxels per output + Dice / CE terms
 Nothing from the reference's source text is stored: only numbers it computed.
 """
 import argparse
@@ -246,6 +248,93 @@ def make_model_f64(name):
     print(f"model_{name}_f64.npz: losses {losses}, {time.time() - t0:.0f}s", flush=True)
 
 
+N_VOX = 2048
+
+
+def _dice_ce_parts64(logits, target):
+    """(Dice term, CE term) of SURVEY 8a row H evaluated in float64 from the given logits (any dtype)."""
+    import torch.nn.functional as F
+    lg = logits.detach().double()
+    n_cls = lg.shape[1]
+    labels = target.squeeze(1).long()
+    p = torch.softmax(lg, dim=1)
+    yy = F.one_hot(labels, n_cls).permute(0, 4, 1, 2, 3).to(p.dtype)
+    inter = (p * yy).sum((2, 3, 4))
+    denom = (yy * yy).sum((2, 3, 4)) + (p * p).sum((2, 3, 4))
+    return (1.0 - 2.0 * inter / (denom + 1e-6)).mean().item(), F.cross_entropy(lg, labels).item()
+
+
+def _targets_for(name, y):
+    t1 = O.downsample_target(y, (0.5, 0.5, 1.0))
+    t2 = O.downsample_target(y, (0.25, 0.25, 0.5))
+    if name.startswith("ctunet"):
+        return [y, t1, t2, y, y]
+    if name.startswith("cunet"):
+        return [y, t1, t2]
+    return [y, y]
+
+
+def make_model_mode(name, mode):
+    """One more pass of the REFERENCE modules over the two golden samples in `mode`:
+         'bf16'  under torch.autocast('cpu', dtype=torch.bfloat16) exactly where the trainer wraps model(data)
+                 (trainer_CTUNet.py:90-91); the loss is evaluated on the up-cast logits (DiceCELoss runs in fp32 under
+                 autocast) -> model_<name>_bf16.npz: sampled logits at the fp32 golden's indices, loss, gradient norms
+                 and sampled gradient entries;
+         'f32' / 'f64'  plain / .double() -> model_<name>_vox32.npz / _vox64.npz.
+       Every mode also stores, per sample and output, the complete 14-logit vectors of N_VOX fixed voxels (argmax
+       agreement) and the Dice and CE terms of that output against its deep-supervision target (float64 evaluation of
+       the stored-precision logits): 'Dice within 1e-4' of the north star is checked on these."""
+    t0 = time.time()
+    ctor, loss_name = MODELS[name]
+    z32 = np.load(os.path.join(HERE, f"model_{name}.npz"), allow_pickle=False)
+    model = ctor()
+    model.load_state_dict({k: O.synthetic_tensor(k, v.shape) for k, v in model.state_dict().items()}, strict=True)
+    if mode == "f64":
+        model = model.double()
+    out, losses = {}, []
+    for s in range(2):
+        x, y = O.synthetic_batch(1, seed=1000 + s)
+        if mode == "bf16":
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                outs = flat_outputs(model(x))
+            assert all(o.dtype == torch.bfloat16 for o in outs)
+            loss = O.LOSSES[loss_name](model_outputs_regroup(name, outs), y)   # casts the logits up itself
+        elif mode == "f64":
+            outs = flat_outputs(model(x.double()))
+            loss = _loss64(loss_name, model_outputs_regroup(name, outs), y)
+        else:
+            outs = flat_outputs(model(x))
+            loss = O.LOSSES[loss_name](model_outputs_regroup(name, outs), y)
+        (0.5 * loss).backward()
+        losses.append(loss.item())
+        for i, (o, t) in enumerate(zip(outs, _targets_for(name, y))):
+            idx = torch.from_numpy(z32[f"s{s}/out{i}/idx"])
+            of = o.detach()
+            if mode == "bf16":
+                out[f"s{s}/out{i}/val_bf16"] = of.flatten()[idx].float().numpy()
+            g = torch.Generator().manual_seed(777 + i)
+            nvox = of[0, 0].numel()
+            vidx = torch.randint(0, nvox, (N_VOX,), generator=g)
+            out[f"s{s}/out{i}/vox_idx"] = vidx.numpy()
+            vox = of[0].reshape(of.shape[1], -1)[:, vidx].t()
+            out[f"s{s}/out{i}/vox"] = (vox.double() if mode == "f64" else vox.float()).numpy()
+            d, c = _dice_ce_parts64(of, t)
+            out[f"s{s}/out{i}/dice_ce"] = np.array([d, c])
+        del outs, loss
+    out["loss_per_sample"] = np.array(losses)
+    out["loss_b2"] = np.array(sum(losses) / 2)
+    if mode == "bf16":
+        pr = dict(model.named_parameters())
+        out["grad/norm_b2"] = np.array([0.0 if pr[str(k)].grad is None else pr[str(k)].grad.double().norm().item()
+                                        for k in z32["grad/keys"]])
+        for j in range(8):
+            k = str(z32[f"grad/sample{j}/key"])
+            out[f"grad/sample{j}/val"] = pr[k].grad.flatten()[torch.from_numpy(z32[f"grad/sample{j}/idx"])].float().numpy()
+    fn = {"bf16": f"model_{name}_bf16.npz", "f32": f"model_{name}_vox32.npz", "f64": f"model_{name}_vox64.npz"}[mode]
+    np.savez_compressed(os.path.join(HERE, fn), **out)
+    print(f"{fn}: losses {losses}, {time.time() - t0:.0f}s", flush=True)
+
+
 def _loss64(loss_name, outs, y):
     """oracle loss composition evaluated in float64 (O.dice_ce_loss casts logits to float32, so restate the cast-free
     form here)."""
@@ -283,7 +372,14 @@ if __name__ == "__main__":
     ap.add_argument("--skip-models", action="store_true")
     ap.add_argument("--only", default=None)
     ap.add_argument("--f64", action="store_true", help="write model_<name>_f64.npz (reference run in float64)")
+    ap.add_argument("--mode", default=None, choices=["bf16", "f32", "f64"],
+                    help="write model_<name>_bf16.npz (reference under CPU autocast) / _vox32.npz / _vox64.npz")
     a = ap.parse_args()
+    if a.mode:
+        for n in MODELS:
+            if a.only is None or a.only == n:
+                make_model_mode(n, a.mode)
+        sys.exit(0)
     if a.f64:
         for n in MODELS:
             if a.only is None or a.only == n:

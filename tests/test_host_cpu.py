@@ -186,3 +186,101 @@ def test_data_parallel_gloo_world2(tmp_path):
     ref = torch.cat([torch.nn.functional.pad(p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel()),
                                              (0, (-p.numel()) % 64)) for p in m.parameters()])
     assert torch.allclose(r0["grad"], ref, atol=1e-6)
+
+
+def test_reference_grad_reset_idiom_does_not_accumulate_across_steps():
+    """the reference loop clears gradients with `param.grad = None` (trainer_CTUNet.py:88-89) and
+    drives torch.optim.AdamW; with DataParallel(model) in between, autograd then installs a fresh .grad every step and
+    the FlatParams hook must COPY it into the flat slice - adding it (round 1) made the flat gradient, and therefore the
+    all-reduced bucket and the update, grow 1x, 2x, 3x ... over the steps."""
+    torch.manual_seed(0)
+    plain = _Toy()
+    wrapped = _Toy()
+    wrapped.load_state_dict(plain.state_dict())
+    dp = train.DataParallel(wrapped)                       # world 1: no process group needed
+    o1 = torch.optim.AdamW(plain.parameters(), lr=1e-2, weight_decay=1e-5)
+    o2 = torch.optim.AdamW(wrapped.parameters(), lr=1e-2, weight_decay=1e-5)
+    g = torch.Generator().manual_seed(3)
+    for step in range(3):
+        x = torch.randn(6, 12, generator=g)
+        for p in plain.parameters():
+            p.grad = None
+        for p in wrapped.parameters():
+            p.grad = None
+        plain(x).pow(2).mean().backward()
+        dp(x).pow(2).mean().backward()
+        dp.finish()
+        for (n, a), b in zip(plain.named_parameters(), wrapped.parameters()):
+            if a.grad is None:
+                assert b.grad is None, n
+            else:
+                assert torch.allclose(a.grad, b.grad, atol=1e-7), (step, n)
+        o1.step()
+        o2.step()
+    for a, b in zip(plain.parameters(), wrapped.parameters()):
+        assert torch.allclose(a, b, atol=1e-6)
+    # torch's own zero_grad(set_to_none=False) idiom keeps working in place too
+    o2.zero_grad(set_to_none=False)
+    assert dp.flat.grad[:dp.flat.offsets[1]].abs().sum() == 0
+
+
+def test_one_flat_owner_per_parameter():
+    """DataParallel(model) followed by FusedAdamW(model.parameters()) used to build a second
+    FlatParams over the same parameters (both folding every gradient).  Now the optimizer adopts the existing owner, and
+    an explicit second FlatParams raises until the first is released."""
+    m = _Toy()
+    dp = train.DataParallel(m)
+    assert train.FlatParams.of(m.parameters()) is dp.flat
+    opt = train.FusedAdamW(m.parameters(), lr=1e-3)
+    assert opt.flat is dp.flat
+    with pytest.raises(RuntimeError, match="already belongs"):
+        train.FlatParams(m.parameters())
+    dp.flat.release()
+    assert train.FlatParams.of(m.parameters()) is None
+    fp2 = train.FlatParams(m.parameters())               # re-homing after an explicit release is allowed
+    m(torch.randn(4, 12)).sum().backward()
+    assert fp2.grad.abs().sum() > 0
+
+
+class _Shared(nn.Module):
+    """One weight used twice in a graph (weight sharing)."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = nn.Linear(8, 8)
+        self.tail = nn.Linear(8, 2)
+
+    def forward(self, x):
+        return self.tail(self.w(torch.tanh(self.w(x))))
+
+
+def test_parameter_used_twice_reports_once_with_the_full_gradient():
+    """The bucket of a parameter may only be reduced after its LAST contribution: autograd sums the uses before
+    AccumulateGrad runs once, so the hook's single report already sees the complete gradient."""
+    torch.manual_seed(1)
+    m = _Shared()
+    ref = _Shared()
+    ref.load_state_dict(m.state_dict())
+    dp = train.DataParallel(m, bucket_mb=0.00001)
+    seen = []
+    at_report = {}
+
+    def listener(i):
+        seen.append(i)
+        p = dp.flat.params[i]
+        at_report[i] = p.grad.detach().clone()
+    dp.flat.listeners.append(listener)
+    x = torch.randn(5, 8)
+    dp(x).pow(2).sum().backward()
+    ref(x).pow(2).sum().backward()
+    dp.finish()
+    assert sorted(seen) == list(range(len(dp.flat.params)))          # exactly one report per parameter
+    for i, p in enumerate(dp.flat.params):
+        r = dict(ref.named_parameters())[[n for n, q in m.named_parameters() if q is p][0]]
+        assert torch.allclose(at_report[i], r.grad, atol=1e-6)       # and it was complete when reported
+
+
+def test_package_synthetic_batch_equals_the_oracle_generator():
+    from oracle import ctunet_oracle as O
+    a, b = H.synthetic_batch(1, size=(8, 8, 8), seed=1003), O.synthetic_batch(1, size=(8, 8, 8), seed=1003)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

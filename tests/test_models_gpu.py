@@ -259,9 +259,10 @@ def test_drop_in_protocol(H):
     assert out[0][0].shape == (4, 14, 96, 96, 96) and out[0][1].shape == (4, 14, 48, 48, 96)
     assert out[0][2].shape == (4, 14, 24, 24, 48) and out[1][0].shape == out[1][1].shape == (4, 14, 96, 96, 96)
     assert out[0][0].dtype == torch.bfloat16 and all(torch.isfinite(o.float()).all() for g in out for o in g)
-    with pytest.raises(NotImplementedError):
-        with torch.autocast("cuda", dtype=torch.float16):
-            m(x[:1])
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16), pytest.warns(UserWarning, match="bfloat16"):
+        o16 = m(x[:1])                                   # the reference's default AMP dtype: accepted, fp16 logits back
+    assert o16[0][0].dtype == torch.float16 and o16[1][1].dtype == torch.float16
+    assert torch.allclose(o16[0][0].float(), out[0][0][:1].float(), atol=2e-2, rtol=2e-2)
     with pytest.raises(RuntimeError):
         m.cpu()(x[:1].cpu())
 
@@ -321,3 +322,38 @@ def test_training_trajectory_follows_the_oracle(H, kind, depth):
         assert abs(g - r) <= 2e-2 * abs(r), (got, ref)
     if kind == "cunet":
         assert ref[2] < ref[0] and got[2] < got[0]      # and it trains (TUNet at lr 1e-3 first bounces up)
+
+
+def test_reference_amp_call_sequence_fp16_autocast_gradscaler(H):
+    """The reference trainer's step with its DEFAULT flags (amp=True): `param.grad = None` -> autocast() [float16] ->
+    logits = model(data) -> five-head loss -> scaler.scale(loss).backward() -> scaler.step(optimizer) -> scaler.update()
+    (trainer_CTUNet.py:88-112), on the HIP model with torch.optim.AdamW.  Written from that call order; no reference code."""
+    import warnings
+    torch.manual_seed(0)
+    m = H.CTUNet(in_channels=1, dim_conv_stem=64, out_channels=14, model_depth=50, img_size=(96, 96), frames=96,
+                 patch_frame=8, num_depths=2).cuda()
+    m.train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=1e-5)
+    scaler = torch.amp.GradScaler("cuda")
+    from oracle.ctunet_oracle import synthetic_batch
+    x, y = synthetic_batch(1, seed=1000)
+    x, y = x.cuda(), y.cuda()
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    losses = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(2):
+            for p in m.parameters():
+                p.grad = None
+            with torch.autocast("cuda", dtype=torch.float16):
+                logits = m(x)
+                assert logits[0][0].dtype == torch.float16
+                loss = H.ctunet_loss(logits, y)
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            losses.append(float(loss))
+    assert all(np.isfinite(losses)) and scaler.get_scale() == 65536.0       # no inf was ever seen: the scale never backed off
+    moved = [k for k, v in m.named_parameters() if v.grad is not None and not torch.equal(v.detach(), before[k])]
+    never = [k for k, v in m.named_parameters() if v.grad is None]
+    assert len(moved) > 150 and all(".conv3." in k for k in never) and len(never) == 7

@@ -85,8 +85,8 @@ def test_linear_stream_kernel(ops, M, K, N, res):
     with a residual in the epilogue) and, through the data gradient of a Linear whose forward weight is read reduction-major,
     its w_kn form (here: K_bwd = N_fwd = 128 for the last case; the other cases' data gradients have K_bwd = N_fwd >= 256
     and stay on the general kernel).  Checked against float64 math like every other GEMM case, and against the general
-    kernel (CTU_NT_NO_STREAM) for equal rounding."""
-    import os
+    kernel (ctu_set_option "route" bit 1) for equal rounding."""
+    from hybrid_ctunet_amd import _lib
     dtype = torch.bfloat16
     _linear_case(ops, dtype, M, K, N, False, 0, res)
     x = rnd((M, K), 1).to(dtype).cuda()
@@ -94,11 +94,11 @@ def test_linear_stream_kernel(ops, M, K, N, res):
     r = rnd((M, N), 4).to(dtype).cuda() if res else None
     with torch.no_grad():
         a = ops.linear(x, w, None, r, 0)
-        os.environ["CTU_NT_NO_STREAM"] = "1"
+        _lib.call("ctu_set_option", b"route", 1)
         try:
             b = ops.linear(x, w, None, r, 0)
         finally:
-            os.environ.pop("CTU_NT_NO_STREAM", None)
+            _lib.call("ctu_set_option", b"route", 0)
     assert torch.equal(a, b)      # same products, same fp32 accumulation order over k, same single rounding to bf16
 
 

@@ -3,17 +3,17 @@ bit-equal every time (a rare race would show as a sporadic mismatch), the sums e
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
-from hybrid_ctunet_amd import ops
+from hybrid_ctunet_amd import ops, _lib
 torch.manual_seed(0)
 bad = 0
 for (M, K, N, B) in [(442368, 128, 512, 2), (442368, 32, 128, 2), (55296, 64, 256, 2), (36864 * 3, 128, 128, 3)]:
     x = torch.randn(M, K, device="cuda").bfloat16()
     w = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
     ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    os.environ["CTU_NT_NO_STREAM"] = "1"
+    _lib.call("ctu_set_option", b"route", 1)
     acc0 = torch.zeros(B * N * 2, device="cuda", dtype=torch.float64)
     ops._plain_gemm(x, w, ref, M, K, N, in_acc=acc0, in_rows=M // B)
-    os.environ.pop("CTU_NT_NO_STREAM")
+    _lib.call("ctu_set_option", b"route", 0)
     torch.cuda.synchronize()
     for it in range(150):
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
