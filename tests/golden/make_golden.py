@@ -100,12 +100,12 @@ def make_blocks():
     out = {}
     run_block(out, "resblock_same", R.ResBlock(3, 16, 16, 3, 1, "instance"), [rnd((2, 16, 6, 8, 8), 1)], 1)
     run_block(out, "resblock_proj", R.ResBlock(3, 32, 16, 3, 1, "instance"), [rnd((1, 32, 8, 6, 8), 2)], 2)
-    run_block(out, "resblock_in1", R.ResBlock(3, 1, 16, 3, 1, "instance"), [rnd((1, 1, 8, 8, 12), 3)], 3)
+    run_block(out, "resblock_in1", R.ResBlock(3, 1, 64, 3, 1, "instance"), [rnd((1, 1, 8, 8, 12), 3)], 3)  # N=64: the width every Cin=1 conv of the models has
     ds = torch.nn.Sequential(RR.get_conv_layer(3, 32, 64, kernel_size=1, stride=(2, 2, 2), conv_only=True),
                              RR.get_norm_layer(name="instance", spatial_dims=3, channels=64))
     run_block(out, "bottleneck_s2", RR.Bottleneck(32, 16, stride=(2, 2, 2), downsample=ds), [rnd((1, 32, 8, 8, 8), 4)], 4)
     run_block(out, "bottleneck_id", RR.Bottleneck(64, 16), [rnd((2, 64, 4, 6, 8), 5)], 5)
-    run_block(out, "stem", RR.get_conv_layer(3, 1, 16, kernel_size=(7, 7, 7), stride=(2, 2, 1), conv_only=True),
+    run_block(out, "stem", RR.get_conv_layer(3, 1, 64, kernel_size=(7, 7, 7), stride=(2, 2, 1), conv_only=True),
               [rnd((1, 1, 12, 12, 10), 6)], 6)
     run_block(out, "convt222", RR.get_conv_layer(3, 32, 16, kernel_size=(2, 2, 2), stride=(2, 2, 2), conv_only=True,
                                                  is_transposed=True), [rnd((1, 32, 3, 4, 5), 7)], 7)

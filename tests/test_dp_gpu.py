@@ -55,7 +55,7 @@ def _worker(rank, world, port, out_dir, kind):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["cunet", "tunet"])
+@pytest.mark.parametrize("kind", ["cunet", "tunet", "ctunet"])  # ctunet = BASELINE config 5's model (depth 50 here)
 def test_two_ranks_on_one_gpu_stay_identical(tmp_path, kind):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), kind), nprocs=2, join=True)
@@ -108,3 +108,49 @@ def test_ctunet_gradients_become_ready_in_bucket_order():
             done.append(max(ks))
     inv = sum(1 for a, b in zip(done, done[1:]) if b < a)
     assert inv <= max(1, len(done) // 5), (inv, done)
+
+
+def test_rccl_bucket_exchange_world1():
+    """ctu_comm_init / ctu_allreduce_bucket over a real RCCL communicator (one rank: the box has one GPU): the fp32 payload
+    (ncclAllReduce, ncclAvg) must leave a bucket unchanged, the bf16 payload (cast -> all-to-all -> fp32 sum -> all-gather
+    -> expand) must return exactly the bf16 rounding of every element, ragged tail included; on a side stream."""
+    from hybrid_ctunet_amd.comm import Communicator
+    comm = Communicator.from_torch()
+    assert comm.world == 1
+    g = torch.Generator().manual_seed(0)
+    for n in (1000003, 8 * 1024 * 1024, 64):
+        x = torch.randn(n, generator=g).cuda()
+        ref = x.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            comm.allreduce_mean(x, "fp32")
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(x, ref)
+        with torch.cuda.stream(side):
+            comm.allreduce_mean(x, "bf16")
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref.to(torch.bfloat16).float())
+    comm.close()
+
+
+def test_shared_weight_gradient_sink_reports_after_the_last_use():
+    """A parameter used by two ops of one graph accumulates twice into its gradient sink; 'gradient complete' (what lets
+    DataParallel launch the bucket's all-reduce) may fire only after the second accumulation (ops.sink_expect)."""
+    import hybrid_ctunet_amd as H
+    from hybrid_ctunet_amd import ops
+    torch.manual_seed(0)
+    w = torch.nn.Parameter((torch.randn(64, 64) * 0.1).cuda())
+    flat = H.FlatParams([w])
+    reports = []
+    flat.listeners.append(lambda i: reports.append(flat.grad.clone()))
+    x = torch.randn(512, 64, device="cuda")
+    flat.zero_grad()
+    h = ops.linear(ops.linear(x, w), w)
+    h.sum().backward()
+    torch.cuda.synchronize()
+    assert len(reports) == 1
+    wr = w.detach().clone().requires_grad_(True)
+    ((x @ wr.t()) @ wr.t()).sum().backward()
+    assert torch.allclose(reports[0][:4096].view(64, 64), wr.grad, rtol=2e-3, atol=2e-3 * wr.grad.abs().max().item())

@@ -63,10 +63,10 @@ def _blocks(H):
         # name: (module factory, input layout) ; layout 'vol' = golden NCDHW -> channels-last, 'last' = as is
         "resblock_same": (lambda: N.ResBlock(3, 16, 16, 3, 1, "instance"), "vol"),
         "resblock_proj": (lambda: N.ResBlock(3, 32, 16, 3, 1, "instance"), "vol"),
-        "resblock_in1": (lambda: N.ResBlock(3, 1, 16, 3, 1, "instance"), "vol"),
+        "resblock_in1": (lambda: N.ResBlock(3, 1, 64, 3, 1, "instance"), "vol"),
         "bottleneck_s2": (lambda: R.Bottleneck(32, 16, stride=(2, 2, 2), downsample=R._Downsample(32, 64, (2, 2, 2))), "vol"),
         "bottleneck_id": (lambda: R.Bottleneck(64, 16), "vol"),
-        "stem": (lambda: R.get_conv_layer(3, 1, 16, kernel_size=(7, 7, 7), stride=(2, 2, 1)), "vol"),
+        "stem": (lambda: R.get_conv_layer(3, 1, 64, kernel_size=(7, 7, 7), stride=(2, 2, 1)), "vol"),
         "convt222": (lambda: R.get_conv_layer(3, 32, 16, kernel_size=(2, 2, 2), stride=(2, 2, 2), is_transposed=True), "vol"),
         "convt221": (lambda: R.get_conv_layer(3, 32, 16, kernel_size=(2, 2, 1), stride=(2, 2, 1), is_transposed=True), "vol"),
         "upcat": (lambda: N.UpCatConvBlock(3, 32, 16, 3, (2, 2, 2), "instance"), "vol"),
@@ -90,9 +90,6 @@ BLOCK_NAMES = ["resblock_same", "resblock_proj", "resblock_in1", "bottleneck_s2"
 def test_block_matches_reference_golden_fp32(H, golden_dir, name):
     z = _npz(golden_dir, "blocks.npz")
     factory, layout = _blocks(H)[name]
-    if name == "stem" or name == "resblock_in1":
-        # the cin==1 kernels want N % 64 == 0; these goldens use N=16 -> covered by test_ops_gpu + whole models
-        pytest.skip("cin1 kernels require N % 64 == 0; covered at N=64 in test_ops_gpu and by the whole-model goldens")
     m = _load_block(factory(), name)
     ins = []
     i = 0
@@ -112,8 +109,8 @@ def test_block_matches_reference_golden_fp32(H, golden_dir, name):
     for j, t in enumerate(ins):
         g = torch.from_numpy(z[f"{name}/gin{j}"])
         g = cl(g) if layout == "vol" else g
-        if name in ("stem",):
-            continue
+        if name in ("stem", "resblock_in1"):
+            continue  # the input of a Cin=1 conv is the image: the product computes no gradient for it (no consumer)
         assert relerr(t.grad, g) <= 2e-3, f"gin{j} {relerr(t.grad, g):.2e}"
     for k, p in m.named_parameters():
         isnone = bool(z[f"{name}/gw_isnone/{k}"])
@@ -228,19 +225,111 @@ def test_whole_model_fp32_matches_reference_golden(H, golden_dir, name):
             assert e_mine <= max(5e-3, 2 * e_ref), (k, e_mine, e_ref)
 
 
+def _dice_term(logits, target):
+    """Dice term of SURVEY 8a row H (mean over (B, C) of 1 - 2 sum(p y) / (sum(y^2) + sum(p^2) + 1e-6)), float64 on the
+    device from the given logits [1, C, D, H, W] - the quantity the north star's 'Dice within 1e-4' speaks of."""
+    lg = logits.detach().double()
+    p = torch.softmax(lg, dim=1)
+    yy = torch.nn.functional.one_hot(target.squeeze(1).long(), lg.shape[1]).permute(0, 4, 1, 2, 3).double()
+    inter = (p * yy).sum((2, 3, 4))
+    denom = (yy * yy).sum((2, 3, 4)) + (p * p).sum((2, 3, 4))
+    return float((1.0 - 2.0 * inter / (denom + 1e-6)).mean())
+
+
+def _rms(got, ref):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return float(np.sqrt(np.mean((got - ref) ** 2)) / max(np.sqrt(np.mean(ref ** 2)), 1e-300))
+
+
 @pytest.mark.parametrize("name", ["ctunet101", "cunet101", "tunet"])
-def test_whole_model_bf16_drift(H, golden_dir, name):
-    """bf16 operands / fp32 accumulate (BASELINE configs 2-4): drift vs the reference-in-fp64 value is REPORTED; the
-    gate is loose and on aggregate quantities (loss, median gradient-norm error) because point-wise logits of the
-    ResNet branch inherit the ~1000x noise amplification (bf16 storage injects 4e-3 per tensor)."""
-    res = _run_model(H, golden_dir, name, "bf16")
-    _report(name, "bf16", res)
-    assert res["loss"][0] <= 2e-2, res["loss"]
-    assert res["gradnorm/median"][0] <= 5e-2, res["gradnorm/median"]
-    if name == "tunet":
-        for k, v in res.items():
-            if k.startswith("s"):
-                assert v[0] <= 5e-2, (k, v)
+def test_whole_model_bf16_against_reference_under_autocast(H, golden_dir, name):
+    """Parity at the BENCHMARK precision (BASELINE configs 2-4, bf16 operands / fp32 accumulate).
+
+    The yardstick is the reference itself: its own modules run under torch.autocast(bfloat16) exactly where the trainer
+    wraps model(data) (trainer_CTUNet.py:90-91; golden model_<name>_bf16.npz) drift from the same modules run in float64
+    by 17-83 % of the tensor maximum on the ResNet-branch logits of this randomly weighted InstanceNorm stack (rms 0.17-0.69)
+    and by 1-2 % on the ViT-branch logits - that is what bf16 storage does to this network, in any implementation.
+    Gate, PER OUTPUT and per sample: the HIP bf16 path may drift from the float64 value at most 1.5x as far as the
+    reference-under-autocast does, in max norm and in rms; its argmax over the 14 classes must agree with the float64
+    argmax on 2048 voxels at least as often as the reference's does (minus 1.5x its disagreement / 1 % slack); and its
+    Dice term must sit within max(1e-4, 1.5x the reference-bf16 distance) of the float64 Dice term.  Loss, gradient
+    norms and sampled gradient entries are gated the same way against the reference-bf16 numbers."""
+    from oracle import ctunet_oracle as O
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    kind, depth = MODELS[name]
+    z = _npz(golden_dir, f"model_{name}.npz")
+    z64 = _npz(golden_dir, f"model_{name}_f64.npz")
+    zb = _npz(golden_dir, f"model_{name}_bf16.npz")
+    v64 = _npz(golden_dir, f"model_{name}_vox64.npz")
+    man = json.load(open(os.path.join(golden_dir, f"manifest_{name}.json")))
+    m = H.build_model(kind, model_depth=depth)
+    if name not in _STATE_CACHE:
+        _STATE_CACHE.clear()
+        _STATE_CACHE[name] = {k: O.synthetic_tensor(k, s) for k, s in man.items()}
+    m.load_state_dict(_STATE_CACHE[name], strict=True)
+    m = m.cuda().set_precision("auto")
+    x0, y0 = O.synthetic_batch(1, seed=1000)
+    x1, y1 = O.synthetic_batch(1, seed=1001)
+    x, y = torch.cat((x0, x1)).cuda(), torch.cat((y0, y1)).cuda()
+    with torch.autocast("cuda", dtype=torch.bfloat16):     # the trainer's wrapping, with the BASELINE dtype
+        outs = m(x)
+        flat = [t for g in outs for t in (g if isinstance(g, tuple) else (g,))]
+        assert all(t.dtype == torch.bfloat16 for t in flat)
+        loss = H.LOSSES[kind](outs, y)
+    loss.backward()
+    torch.cuda.synchronize()
+    t1 = O.downsample_target(y, (0.5, 0.5, 1.0))
+    t2 = O.downsample_target(y, (0.25, 0.25, 0.5))
+    targets = {"ctunet": [y, t1, t2, y, y], "cunet": [y, t1, t2], "tunet": [y, y]}[kind]
+    print(f"\n{name} bf16: quantity | HIP-bf16 vs ref-fp64 | ref-bf16(autocast) vs ref-fp64      [max-norm, rms]")
+    fails = []
+    for s in range(2):
+        for i, o in enumerate(flat):
+            r64, rb = z64[f"s{s}/out{i}/val64"], zb[f"s{s}/out{i}/val_bf16"]
+            got = o[s].detach().float().flatten()[torch.from_numpy(z[f"s{s}/out{i}/idx"]).cuda()].cpu().numpy()
+            em, er = (_rel(got, r64), _rms(got, r64)), (_rel(rb, r64), _rms(rb, r64))
+            vidx = torch.from_numpy(v64[f"s{s}/out{i}/vox_idx"]).cuda()
+            vox = o[s].detach().float().reshape(o.shape[1], -1)[:, vidx].t().cpu().numpy()
+            a64 = v64[f"s{s}/out{i}/vox"].argmax(1)
+            agree_m = float((vox.argmax(1) == a64).mean())
+            agree_r = float((zb[f"s{s}/out{i}/vox"].argmax(1) == a64).mean())
+            d64, db = float(v64[f"s{s}/out{i}/dice_ce"][0]), float(zb[f"s{s}/out{i}/dice_ce"][0])
+            dm = _dice_term(o[s:s + 1], targets[i][s:s + 1])
+            print(f"  s{s}/out{i}  max {em[0]:.3e} / {er[0]:.3e}   rms {em[1]:.3e} / {er[1]:.3e}   argmax agreement "
+                  f"{agree_m:.3f} / {agree_r:.3f}   Dice term {dm:.6f} / {db:.6f} (fp64 {d64:.6f})")
+            if em[0] > 1.5 * er[0] or em[1] > 1.5 * er[1]:
+                fails.append((f"s{s}/out{i} drift", em, er))
+            if (1.0 - agree_m) > 1.5 * (1.0 - agree_r) + 0.01:
+                fails.append((f"s{s}/out{i} argmax", agree_m, agree_r))
+            if abs(dm - d64) > max(1e-4, 1.5 * abs(db - d64)):
+                fails.append((f"s{s}/out{i} dice", dm, db, d64))
+    l64, lb = float(z64["loss_b2_64"]), float(zb["loss_b2"])
+    print(f"  loss {loss.item():.6f}  ref-bf16 {lb:.6f}  ref-fp64 {l64:.6f}")
+    if abs(loss.item() - l64) > max(1e-3 * l64, 1.5 * abs(lb - l64)):
+        fails.append(("loss", loss.item(), lb, l64))
+    pr = dict(m.named_parameters())
+    mine, ref = [], []
+    for k, nb, n64, isnone in zip(z["grad/keys"], zb["grad/norm_b2"], z64["grad/norm_b2_64"], z["grad/isnone"]):
+        g = pr[str(k)].grad
+        if isnone:
+            assert g is None or float(g.abs().max()) == 0.0, f"{k} should receive no gradient"
+            continue
+        mine.append(abs(g.double().norm().item() - n64) / max(n64, 1e-300))
+        ref.append(abs(nb - n64) / max(n64, 1e-300))
+    print(f"  gradient norms: median err {np.median(mine):.3e} / {np.median(ref):.3e}   max {max(mine):.3e} / {max(ref):.3e}")
+    if np.median(mine) > max(5e-3, 1.5 * np.median(ref)) or max(mine) > max(5e-2, 1.5 * max(ref)):
+        fails.append(("gradnorm", float(np.median(mine)), float(np.median(ref)), max(mine), max(ref)))
+    for j in range(8):
+        k = str(z[f"grad/sample{j}/key"])
+        got = pr[k].grad.flatten()[torch.from_numpy(z[f"grad/sample{j}/idx"]).cuda()].cpu().numpy()
+        rb, r64 = zb[f"grad/sample{j}/val"], z64[f"grad/sample{j}/val64"]
+        em, er = _rms(got, r64), _rms(rb, r64)
+        print(f"  grad sample {k:58s} rms {em:.3e} / {er:.3e}")
+        if em > max(2e-2, 1.5 * er):
+            fails.append((f"gradsample {k}", em, er))
+    assert not fails, fails
 
 
 def test_drop_in_protocol(H):
@@ -357,3 +446,89 @@ def test_reference_amp_call_sequence_fp16_autocast_gradscaler(H):
     moved = [k for k, v in m.named_parameters() if v.grad is not None and not torch.equal(v.detach(), before[k])]
     never = [k for k, v in m.named_parameters() if v.grad is None]
     assert len(moved) > 150 and all(".conv3." in k for k in never) and len(never) == 7
+
+
+def test_stagewise_bf16_drift_teacher_forced(H):
+    """Where would a wrong bf16 kernel hide?  Whole-model bf16 logits of the ResNet branch are decorrelated by the
+    InstanceNorm stack's noise amplification whatever the implementation (see the test above), so a bf16-only kernel
+    bug could not be told from that noise there.  Here every stage of CTUNet d101 is run ALONE on the HIP bf16 path from
+    the fp32 ORACLE's input activations of that stage (teacher forcing: drift cannot accumulate from stage to stage)
+    and compared with the oracle's output of the same stage.  One stage = 3-13 bottlenecks / one fusion decoder /
+    the ViT trunk / the window-attention pyramid: its bf16 drift is a few per cent rms; a broken kernel shows up as a
+    stage far above its neighbours.  Forward only, one 96^3 volume."""
+    from oracle import ctunet_oracle as O
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    orac = O.build("ctunet")
+    sd = {k: O.synthetic_tensor(k, v.shape) for k, v in orac.state_dict().items()}
+    orac.load_state_dict(sd)
+    prod = H.build_model("ctunet")
+    prod.load_state_dict(sd, strict=True)
+    prod = prod.cuda()
+    x, _ = O.synthetic_batch(1, seed=1000)
+    cap = {}
+
+    def grab(name):
+        def hook(mod, args, out):
+            cap[name] = (args, out)
+        return hook
+    names = ["convnet.layer1", "convnet.layer2", "convnet.layer3", "convnet.layer4", "res_decoder3", "res_decoder2",
+             "res_decoder1", "res_decoder0", "vit", "vit_encoder0", "vit_encoder", "vit_decoder0", "res_out", "vit_out"]
+    mods = dict(orac.named_modules())
+    handles = [mods[n].register_forward_hook(grab(n)) for n in names]
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    try:
+        with torch.no_grad():
+            orac(x)
+    finally:
+        torch.set_num_threads(threads)
+        for h in handles:
+            h.remove()
+
+    def dev(t):   # oracle NCDHW fp32 -> channels-last bf16 on the device
+        return t.permute(0, 2, 3, 4, 1).contiguous().cuda().to(torch.bfloat16)
+
+    def back(t):  # channels-last device -> NCDHW fp32 host
+        return t.detach().float().permute(0, 4, 1, 2, 3).cpu()
+
+    from hybrid_ctunet_amd import ops
+    rows = []
+
+    def check(stage, got, ref):
+        got, ref = got.double(), ref.double()
+        rms = float(((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-30)))
+        mx = float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+        rows.append((stage, rms, mx))
+
+    with torch.no_grad():
+        xd = dev(x)
+        check("stem (7x7x7 conv + IN + LReLU)", back(ops.instance_norm(prod.convnet.conv1(xd), None, True)),
+              cap["convnet.layer1"][0][0])
+        for k in (1, 2, 3, 4):
+            n = f"convnet.layer{k}"
+            check(n, back(getattr(prod.convnet, f"layer{k}")(dev(cap[n][0][0]))), cap[n][1])
+        for k in (3, 2, 1):
+            n = f"res_decoder{k}"
+            a = cap[n][0]
+            check(n + " (fusion)", back(getattr(prod, n)(dev(a[0]), dev(a[1]), dev(a[2]))), cap[n][1])
+        check("res_decoder0", back(prod.res_decoder0(dev(cap["res_decoder0"][0][0]))), cap["res_decoder0"][1])
+        tok = prod.vit(xd[..., 0])
+        check("vit trunk (12 blocks)", tok.float().cpu(), cap["vit"][1])
+        check("vit_encoder0", back(prod.vit_encoder0(xd)), cap["vit_encoder0"][1])
+        feats = prod.vit_encoder(prod.proj_feat(cap["vit"][1].cuda().to(torch.bfloat16).contiguous()))
+        for i in range(1, 5):
+            check(f"vit_encoder stage {i - 1} output", back(feats[i]), cap["vit_encoder"][1][i])
+        a = cap["vit_decoder0"][0]
+        check("vit_decoder0", back(prod.vit_decoder0(dev(a[0]), dev(a[1]))), cap["vit_decoder0"][1])
+        check("res_out head", prod.res_out(dev(cap["res_out"][0][0])).float().cpu(), cap["res_out"][1])
+        check("vit_out head", prod.vit_out(dev(cap["vit_out"][0][0])).float().cpu(), cap["vit_out"][1])
+    torch.cuda.synchronize()
+    print("\nstage-wise bf16 drift, teacher-forced from the fp32 oracle (CTUNet d101, one volume): rel rms | rel max")
+    for stage, rms, mx in rows:
+        print(f"  {stage:38s} {rms:.3e}  {mx:.3e}")
+    # gates: ~2x what a healthy bf16 stage measures on the MI355X (values recorded in DESIGN.md section 5)
+    limits = {"convnet.layer1": 0.08, "convnet.layer2": 0.08, "convnet.layer3": 0.12, "convnet.layer4": 0.05}
+    for stage, rms, mx in rows:
+        assert rms <= limits.get(stage, 0.05), (stage, rms, mx)
