@@ -84,6 +84,20 @@ __global__ __launch_bounds__(256) void conv3_halo_kernel(const HaloArgs p) {
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // fp32 parity mode: the MFMA chain of one tap (32 products, exact f32 FMAs) is added into a float64 accumulator and
+  // restarted.  A single f32 chain over K = 27 x C (1728 .. 27648 terms) carries a rounding error of ~sqrt(K) ulp-sized
+  // steps relative to the RUNNING sum - the dominant noise source of this network in fp32 (the InstanceNorm stack
+  // amplifies it ~1000x); restarted chains keep it at the level of the final rounding.
+  constexpr bool WIDE = sizeof(T) == 4;
+  double acc64[WIDE ? 2 : 1][WIDE ? NT : 1][WIDE ? 16 : 1];
+  if (WIDE) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc64[i][j][e] = 0.0;
+  }
 
   for (int ch = 0; ch < nchunks; ++ch) {
     const int c0 = ch * CK;
@@ -131,7 +145,26 @@ __global__ __launch_bounds__(256) void conv3_halo_kernel(const HaloArgs p) {
       step(tap, 0, fb0);
       if (tap + 1 < 27) load_b(2 * tap + 2, fb0);
       step(tap, 1, fb1);
+      if (WIDE) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              acc64[i][j][e] += (double)acc[i][j][e];
+              acc[i][j][e] = 0.f;
+            }
+      }
     }
+  }
+  if (WIDE) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = (float)acc64[i][j][e];
   }
 
   // ---- epilogue: per (row tile, n tile): accumulators -> wave-private LDS tile -> 8-wide vectors -> global ----
@@ -526,7 +559,7 @@ static int launch_halo(const HaloArgs& p, float* ws, int64_t ws_floats, hipStrea
   if (HaloDma<T>::launch(p, ws, ws_floats, s)) return ctu_check_launch("conv3_halo");
   const int ntn = p.ntn;
   const int bricks = p.B * p.nbd * p.nbh * p.nbw;
-  if (ntn >= 4 && ntn % 4 == 0)
+  if (ntn >= 4 && ntn % 4 == 0 && sizeof(T) == 2)  // (fp32 mode keeps float64 accumulators: two n tiles per wave at most)
     hipLaunchKernelGGL((conv3_halo_kernel<T, 4>), dim3(bricks, ntn / 4), dim3(256), 0, s, p);
   else if (ntn % 2 == 0)
     hipLaunchKernelGGL((conv3_halo_kernel<T, 2>), dim3(bricks, ntn / 2), dim3(256), 0, s, p);
@@ -608,6 +641,15 @@ __global__ __launch_bounds__(256) void conv3_halo_wgrad_kernel(const HaloWgArgs 
   for (int i = 0; i < 7; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  // fp32 parity mode: per-brick f32 chains (256 voxels) summed in float64 (see conv3_halo_kernel)
+  constexpr bool WIDE = sizeof(T) == 4;
+  double acc64[WIDE ? 7 : 1][WIDE ? 16 : 1];
+  if (WIDE) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc64[i][e] = 0.0;
+  }
 
   const int brick_begin = blockIdx.y * p.bricks_per_block;
   const int brick_end = min(p.nbricks, brick_begin + p.bricks_per_block);
@@ -656,6 +698,21 @@ __global__ __launch_bounds__(256) void conv3_halo_wgrad_kernel(const HaloWgArgs 
         }
       }
     }
+    if (WIDE) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          acc64[i][e] += (double)acc[i][e];
+          acc[i][e] = 0.f;
+        }
+    }
+  }
+  if (WIDE) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = (float)acc64[i][e];
   }
 #pragma unroll
   for (int i = 0; i < 7; ++i) {

@@ -122,6 +122,19 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtArgs p) {
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // fp32 parity mode: every 32-term f32 MFMA chain is added into a float64 accumulator and restarted (conv3_halo.hip
+  // explains why: the f32 reference's own accumulation noise, amplified ~1000x by the InstanceNorm stack, is what the
+  // 1e-3 gate is measured against - the parity path must sit clearly below it)
+  constexpr bool WIDE = sizeof(T) == 4;
+  double acc64[WIDE ? 2 : 1][WIDE ? NJ : 1][WIDE ? 16 : 1];
+  if (WIDE) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc64[i][j][e] = 0.0;
+  }
 
   // split-K: blockIdx.y owns a contiguous range of (tap, k-chunk) iterations; partial tiles are summed in `ws`
   const int it0 = blockIdx.y * p.its_per_split;
@@ -146,8 +159,27 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtArgs p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) Mma<T>::mma(fa[i], fb[j], acc[i][j]);
     }
+    if (WIDE) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            acc64[i][j][e] += (double)acc[i][j][e];
+            acc[i][j][e] = 0.f;
+          }
+    }
     if (it + 1 < n_it) store_tiles(buf ^ 1);
     __syncthreads();
+  }
+  if (WIDE) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = (float)acc64[i][j][e];
   }
 
   // ---- epilogue: accumulators -> LDS (fp32) -> 8-wide row vectors -> bias / GELU / residual -> global ----
@@ -508,6 +540,17 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnArgs a) {
     for (int j = 0; j < AJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // fp32 parity mode: per-iteration f32 chains summed in float64 (see igemm_nt_kernel)
+  constexpr bool WIDE = sizeof(T) == 4;
+  double acc64[WIDE ? AI : 1][WIDE ? AJ : 1][WIDE ? 16 : 1];
+  if (WIDE) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+#pragma unroll
+      for (int j = 0; j < AJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc64[i][j][e] = 0.0;
+  }
 
   if (m_begin < m_end) {
     load_tiles(m_begin);
@@ -530,10 +573,29 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnArgs a) {
 #pragma unroll
           for (int j = 0; j < AJ; ++j) Mma<T>::mma(fa[i], fb[j], acc[i][j]);
       }
+      if (WIDE) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+#pragma unroll
+          for (int j = 0; j < AJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              acc64[i][j][e] += (double)acc[i][j][e];
+              acc[i][j][e] = 0.f;
+            }
+      }
       if (more) store_tiles(buf ^ 1);
       __syncthreads();
       buf ^= 1;
     }
+  }
+  if (WIDE) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+#pragma unroll
+      for (int j = 0; j < AJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = (float)acc64[i][j][e];
   }
   // the four waves hold partial tiles over different 16-row slices: sum them in LDS (ds_add_f32), then ONE global
   // update per element and workgroup (global float atomics run at ~1.3 TB/s chip-wide: 4x fewer bytes matter)
