@@ -17,6 +17,7 @@ SOURCES = ["igemm.hip", "gemm_dma.hip", "conv3_halo.hip", "norm_elementwise.hip"
            "loss_optim.hip", "infer.hip", "dropout.hip", "comm.hip", "philox.h", "mma.h", "dma.h", "gemm_dma.h", "attn_common.h", "common.h"]
 
 CTU_F32, CTU_BF16 = 0, 1
+LAYOUT_NDHWC, LAYOUT_B16 = 0, 1
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 
@@ -44,9 +45,9 @@ class AttnGeom(C.Structure):
 _SIGS = {
     "ctu_igemm_nt": [_i32, _vp, _vp, _vp, _vp, C.POINTER(Geom), C.POINTER(Epilogue), _vp],
     "ctu_igemm_tn": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, C.POINTER(Geom), _vp, _i64, _vp],
-    "ctu_conv3_halo": [_i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 10 + [_vp, _vp, _vp, _i64, _vp],
+    "ctu_conv3_halo": [_i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 10 + [_vp, _vp, _vp, _i64, _i32, _vp],
     "ctu_in_finalize": [_i32, _i64, _i32, _vp, _vp, _vp],
-    "ctu_conv3_halo_wgrad": [_i32, _vp, _vp, _vp, _vp] + [_i32] * 7 + [_vp],
+    "ctu_conv3_halo_wgrad": [_i32, _vp, _vp, _vp, _vp] + [_i32] * 9 + [_vp],
     "ctu_pack_frag": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp],
     "ctu_pack_frag_batched": [_vp, _i32, _i64, _vp],
     "ctu_im2col_cin1": [_vp, _vp, C.POINTER(Geom), _i32, _vp],
@@ -56,9 +57,9 @@ _SIGS = {
     "ctu_colsum": [_i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
     "ctu_outer_rows": [_i32, _vp, _vp, _vp, _i64, _i32, _vp],
     "ctu_in_stats": [_i32, _vp, _i32, _i64, _i32, _vp, _vp, _vp],
-    "ctu_in_apply": [_i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp],
+    "ctu_in_apply": [_i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp],
     "ctu_in_bwd_reduce": [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp],
-    "ctu_in_bwd_apply": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i32, _vp],
+    "ctu_in_bwd_apply": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i32, _i32, _vp],
     "ctu_layernorm_fwd": [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "ctu_layernorm_bwd": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "ctu_layernorm_bwd_add": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
@@ -128,7 +129,7 @@ def lib():
         L.ctu_allreduce_scratch_bytes.argtypes = [_i32, _i64]
         L.ctu_allreduce_scratch_bytes.restype = _i64
         L.ctu_last_error.restype = C.c_char_p
-        if L.ctu_abi_version() != 2:
+        if L.ctu_abi_version() != 3:
             raise RuntimeError("libctunet_hip.so ABI version mismatch")
         _lib = L
     return _lib

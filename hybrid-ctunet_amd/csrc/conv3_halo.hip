@@ -35,6 +35,12 @@ struct HaloArgs {
   const void* residual;    // optional [rows][ldc] (same dtype): added to the result (bf16 DMA kernel, n_split == 0)
   float* part;             // split over input channels (small volumes): fp32 partial outputs [split][rows][ntn * 32], else NULL
   int hc_per_split;        // 16-channel half chunks per split (blockIdx.z)
+  // source layout of x1 (bf16 DMA kernel): element (voxel m, channel c) sits at m * vs1 + (c >> 4) * bs1 + (c & 15).
+  // channels-last: vs1 = C1, bs1 = 16.  CTU_LAYOUT_B16 ("[C/16][voxels][16]", written by ctu_in_apply / ctu_in_bwd_apply for
+  // exactly this consumer): vs1 = 16, bs1 = 16 * voxels - a halo row of 10 voxels is then ONE 320-byte run instead of ten
+  // 32-byte pieces of ten different cache lines.
+  int vs1;
+  int64_t bs1;
   int debug;               // measurement hook (ctu_set_option "nt_debug"): 1 = no output stores, 4 = no weight DMA, 8 = no halo DMA
 };
 
@@ -282,12 +288,13 @@ __global__ __launch_bounds__(256, RD == 2 ? 3 : 2) void conv3_halo_dma_kernel(co
     const int c0 = hc * 16;
     const bool first = c0 < p.C1;
     const bf16* src = first ? x1 : x2;
-    const int cs = first ? p.C1 : p.C2;
+    const int vs = first ? p.vs1 : p.C2;
     const int cc = first ? c0 : c0 - p.C1;
+    src += first ? (size_t)(cc >> 4) * p.bs1 : (size_t)cc;
     unsigned char* dst = smem + (hc & 1) * HBUF;
 #pragma unroll
     for (int k = 0; k < HINS; ++k) {
-      const bf16* g = hm[k] >= 0 ? src + (size_t)hm[k] * cs + cc + ((hpart >> k) & 1) * 8
+      const bf16* g = hm[k] >= 0 ? src + (size_t)hm[k] * vs + ((hpart >> k) & 1) * 8
                                  : reinterpret_cast<const bf16*>(g_zero16);
       dma16(g, dst + k * 1024);
     }
@@ -571,7 +578,7 @@ static int launch_halo(const HaloArgs& p, float* ws, int64_t ws_floats, hipStrea
 extern "C" int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, const void* wfrag, void* out, void* out2,
                               int32_t B, int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N,
                               int32_t n_split, int32_t ldc, int32_t ldc2, double* in_acc, const void* residual, float* ws,
-                              int64_t ws_floats, ctu_stream_t stream) {
+                              int64_t ws_floats, int32_t x1_layout, ctu_stream_t stream) {
   CTU_REQUIRE(x1 && wfrag && out, "conv3_halo: null pointer");
   CTU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3_halo: bad dims");
   CTU_REQUIRE(C1 > 0 && C1 % 32 == 0 && C2 >= 0 && C2 % 32 == 0 && (C2 == 0 || x2), "conv3_halo: C1, C2 must be multiples of 32");
@@ -587,6 +594,11 @@ extern "C" int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, c
               "conv3_halo: a residual input needs the bf16 LDS-DMA kernel without split / statistics");
   p.part = nullptr;
   p.hc_per_split = (C1 + C2) / 16;
+  CTU_REQUIRE(x1_layout == CTU_LAYOUT_NDHWC || (x1_layout == CTU_LAYOUT_B16 && dtype == CTU_BF16 &&
+                                               (int64_t)B * D * H * W * (C1 > C2 ? C1 : C2) < (1ll << 31)),
+              "conv3_halo: the blocked input layout needs the bf16 LDS-DMA kernel");
+  p.vs1 = x1_layout == CTU_LAYOUT_B16 ? 16 : C1;
+  p.bs1 = x1_layout == CTU_LAYOUT_B16 ? (int64_t)16 * B * D * H * W : 16;
   CTU_REQUIRE(ws_floats >= 0 && (ws_floats == 0 || ws), "conv3_halo: bad workspace");
   CTU_REQUIRE(!in_acc || (dtype == CTU_BF16 && n_split == 0 &&
                           (int64_t)B * D * H * W * (C1 > C2 ? C1 : C2) < (1ll << 31)),
@@ -612,6 +624,8 @@ struct HaloWgArgs {
   float* dw;  // [27][N][K]
   int B, D, H, W, C1, C2, N;
   int nbd, nbh, nbw, nbricks, bricks_per_block, tiles_c, tiles_n;
+  int xvs, yvs;      // voxel strides of x1 and dy (bf16 DMA kernel), see HaloArgs::vs1
+  int64_t xbs, ybs;  // 16-channel-block strides
   int debug;  // measurement hook (ctu_set_option "nt_debug"): 4 = no operand DMA
 };
 
@@ -761,7 +775,8 @@ __global__ __launch_bounds__(512, 1) void conv3_halo_wgrad_dma_kernel(const Halo
   const int K = p.C1 + p.C2;
   const bool first = c0 < p.C1;
   const bf16* src = first ? reinterpret_cast<const bf16*>(p.x1) : reinterpret_cast<const bf16*>(p.x2);
-  const int cs = first ? p.C1 : p.C2;
+  const int cs = first ? p.xvs : p.C2;                       // voxel stride of the halo operand
+  const int64_t cbs = first ? p.xbs : 16;                    // its 16-channel-block stride
   const int cc = first ? c0 : c0 - p.C1;
   const bf16* dy = reinterpret_cast<const bf16*>(p.dy);
   const bf16* zero = reinterpret_cast<const bf16*>(g_zero16);
@@ -794,7 +809,8 @@ __global__ __launch_bounds__(512, 1) void conv3_halo_wgrad_dma_kernel(const Halo
         const bool ok = hv[k] >= 0 && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
                         (unsigned)gw < (unsigned)p.W;
         const int m = ((b * p.D + gd) * p.H + gh) * p.W + gw;
-        dma16(ok ? src + (size_t)m * cs + cc + ((hv[k] >> 12) & 3) * 8 : zero, dst + i * 1024);
+        const int ch = cc + ((hv[k] >> 12) & 3) * 8;  // first of this lane's 8 channels
+        dma16(ok ? src + (size_t)m * cs + (size_t)(ch >> 4) * cbs + (ch & 15) : zero, dst + i * 1024);
       }
     }
 #pragma unroll
@@ -806,7 +822,7 @@ __global__ __launch_bounds__(512, 1) void conv3_halo_wgrad_dma_kernel(const Halo
       const int n = n0 + (j >> 4) * 32 + (S & 3) * 8;
       const bool ok = gd < p.D && gh < p.H && gw < p.W && n < p.N;
       const int m = ((b * p.D + gd) * p.H + gh) * p.W + gw;
-      dma16(ok ? dy + (size_t)m * p.N + n : zero, dst + HBYTES + j * 1024);
+      dma16(ok ? dy + (size_t)m * p.yvs + (size_t)(n >> 4) * p.ybs + (n & 15) : zero, dst + HBYTES + j * 1024);
     }
   };
 
@@ -863,7 +879,7 @@ __global__ __launch_bounds__(512, 1) void conv3_halo_wgrad_dma_kernel(const Halo
 
 extern "C" int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void* x1, const void* x2, float* dw, int32_t B,
                                     int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N,
-                                    ctu_stream_t stream) {
+                                    int32_t x1_layout, int32_t dy_layout, ctu_stream_t stream) {
   CTU_REQUIRE(dy && x1 && dw, "conv3_halo_wgrad: null pointer");
   CTU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3_halo_wgrad: bad dims");
   CTU_REQUIRE(C1 > 0 && C1 % 32 == 0 && C2 >= 0 && C2 % 32 == 0 && (C2 == 0 || x2), "conv3_halo_wgrad: C1, C2 %% 32");
@@ -879,7 +895,16 @@ extern "C" int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void*
   p.tiles_c = (C1 + C2) / 32;
   hipStream_t s = (hipStream_t)stream;
   const int cmax = (C1 > C2 ? C1 : C2) > N ? (C1 > C2 ? C1 : C2) : N;
-  if (dtype == CTU_BF16 && nbricks * 256 * cmax < (1ll << 31)) {
+  const bool dma_ok = dtype == CTU_BF16 && nbricks * 256 * cmax < (1ll << 31);
+  CTU_REQUIRE((x1_layout == CTU_LAYOUT_NDHWC && dy_layout == CTU_LAYOUT_NDHWC) ||
+                  (dma_ok && x1_layout <= CTU_LAYOUT_B16 && dy_layout <= CTU_LAYOUT_B16 && x1_layout >= 0 && dy_layout >= 0),
+              "conv3_halo_wgrad: blocked operand layouts need the bf16 LDS-DMA kernel");
+  const int64_t vox = (int64_t)B * D * H * W;
+  p.xvs = x1_layout == CTU_LAYOUT_B16 ? 16 : C1;
+  p.xbs = x1_layout == CTU_LAYOUT_B16 ? 16 * vox : 16;
+  p.yvs = dy_layout == CTU_LAYOUT_B16 ? 16 : N;
+  p.ybs = dy_layout == CTU_LAYOUT_B16 ? 16 * vox : 16;
+  if (dma_ok) {
     // LDS-DMA kernel: one resident workgroup per CU (256 CUs), 32-bit element offsets
     const int ntn = N > 32 ? 2 : 1;
     p.tiles_n = (N + 32 * ntn - 1) / (32 * ntn);

@@ -95,7 +95,7 @@ __device__ __forceinline__ void in_mean_rstd(const float* stats, int b, int C, i
 template <typename T>
 __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
                                                        const T* __restrict__ res, T* __restrict__ y, const int64_t S,
-                                                       const int C, const int act) {
+                                                       const int C, const int act, const int64_t yb16) {
   const int ncg = C >> 3;
   const int b = blockIdx.y;
   const int64_t nvec = S * ncg;
@@ -106,6 +106,8 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, 
   in_mean_rstd(stats, b, C, cg * 8, 0.f, mean, rstd);
   const size_t base = (size_t)b * S * C;
   x += base;
+  // yb16 > 0 (= voxels of the whole batch): y in CTU_LAYOUT_B16, element (m, c) at ((c >> 4) * yb16 + m) * 16 + (c & 15)
+  T* yblk = y + ((size_t)(cg >> 1) * yb16 + (size_t)b * S) * 16 + (cg & 1) * 8;
   y += base;
   if (res) res += base;
   for (int64_t i = i0; i < nvec; i += stride) {
@@ -123,7 +125,8 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * LRELU_SLOPE;
     }
-    store8(y + i * 8, v);
+    if (yb16) store8(yblk + (i / ncg) * 16, v);
+    else store8(y + i * 8, v);
   }
 }
 
@@ -194,7 +197,8 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
                                                            const T* __restrict__ y, const float* __restrict__ stats,
                                                            const double* __restrict__ sums, T* __restrict__ dx,
                                                            T* __restrict__ dres, const int64_t S, const int C,
-                                                           const int act, double* __restrict__ clear, const int clear_n) {
+                                                           const int act, double* __restrict__ clear, const int clear_n,
+                                                           const int64_t dxb16) {
   const int ncg = C >> 3;
   const int b = blockIdx.y;
   const int64_t nvec = S * ncg;
@@ -214,6 +218,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
   const size_t base = (size_t)b * S * C;
   dy += base;
   x += base;
+  T* dxblk = dx + ((size_t)(cg >> 1) * dxb16 + (size_t)b * S) * 16 + (cg & 1) * 8;  // CTU_LAYOUT_B16 destination (dxb16 > 0)
   dx += base;
   if (y) y += base;
   if (dres) dres += base;
@@ -238,7 +243,8 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = rstd[e] * (g[e] - m1[e] - xh[e] * m2[e]);
-    store8(dx + i * 8, o);
+    if (dxb16) store8(dxblk + (i / ncg) * 16, o);
+    else store8(dx + i * 8, o);
   }
 }
 
@@ -302,16 +308,18 @@ extern "C" int ctu_in_finalize(int32_t B, int64_t S, int32_t C, double* acc, flo
 }
 
 extern "C" int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, const void* residual, void* y,
-                            int32_t B, int64_t S, int32_t C, int32_t act, ctu_stream_t stream) {
+                            int32_t B, int64_t S, int32_t C, int32_t act, int32_t y_layout, ctu_stream_t stream) {
   if (int rc = check_in(x, B, S, C)) return rc;
   CTU_REQUIRE(stats && y, "null pointer");
+  CTU_REQUIRE(y_layout == CTU_LAYOUT_NDHWC || (y_layout == CTU_LAYOUT_B16 && C % 16 == 0 && y != x), "in_apply: bad output layout");
+  const int64_t yb16 = y_layout == CTU_LAYOUT_B16 ? (int64_t)B * S : 0;
   const dim3 grid(in_stream_grid(S, C, B), B);
   hipStream_t s = (hipStream_t)stream;
   CTU_DISPATCH(dtype,
                hipLaunchKernelGGL(in_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, stats,
-                                  (const float*)residual, (float*)y, S, C, act),
+                                  (const float*)residual, (float*)y, S, C, act, yb16),
                hipLaunchKernelGGL(in_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, stats,
-                                  (const bf16*)residual, (bf16*)y, S, C, act));
+                                  (const bf16*)residual, (bf16*)y, S, C, act, yb16));
   return ctu_check_launch("in_apply");
 }
 
@@ -332,17 +340,20 @@ extern "C" int ctu_in_bwd_reduce(ctu_dtype dtype, const void* dy, const void* x,
 
 extern "C" int ctu_in_bwd_apply(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
                                 const double* sums, void* dx, void* dres, int32_t B, int64_t S, int32_t C, int32_t act,
-                                double* clear_ws, int32_t clear_n, ctu_stream_t stream) {
+                                double* clear_ws, int32_t clear_n, int32_t dx_layout, ctu_stream_t stream) {
   if (int rc = check_in(x, B, S, C)) return rc;
   CTU_REQUIRE(dy && stats && sums && dx, "null pointer");
+  CTU_REQUIRE(dx_layout == CTU_LAYOUT_NDHWC || (dx_layout == CTU_LAYOUT_B16 && C % 16 == 0 && dx != dy && dx != x),
+              "in_bwd_apply: bad output layout");
+  const int64_t dxb16 = dx_layout == CTU_LAYOUT_B16 ? (int64_t)B * S : 0;
   CTU_REQUIRE(clear_n >= 0 && (clear_n == 0 || clear_ws) && clear_ws != sums, "bad clear workspace");
   const dim3 grid(in_stream_grid(S, C, B), B);
   hipStream_t s = (hipStream_t)stream;
   CTU_DISPATCH(dtype,
                hipLaunchKernelGGL(in_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x,
-                                  (const float*)y, stats, sums, (float*)dx, (float*)dres, S, C, act, clear_ws, clear_n),
+                                  (const float*)y, stats, sums, (float*)dx, (float*)dres, S, C, act, clear_ws, clear_n, dxb16),
                hipLaunchKernelGGL(in_bwd_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, (const bf16*)x,
-                                  (const bf16*)y, stats, sums, (bf16*)dx, (bf16*)dres, S, C, act, clear_ws, clear_n));
+                                  (const bf16*)y, stats, sums, (bf16*)dx, (bf16*)dres, S, C, act, clear_ws, clear_n, dxb16));
   return ctu_check_launch("in_bwd_apply");
 }
 

@@ -21,13 +21,12 @@ import warnings
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 from .resnet import check_norm, generate_model as resnet, get_conv_layer
 from .vit import ViT, _check_dropout, feed_forward
 
-LOGIT_PAD = 16  # logits are computed with N padded to 16 columns (MFMA/vector width); only the first n_cls are exposed
+LOGIT_PAD = ops.LOGIT_PAD  # logits are computed with N padded to 16 columns (MFMA/vector width); only the first n_cls are exposed
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -55,7 +54,10 @@ class ResBlock(nn.Module):
         # identity shortcut: its gradient is folded into conv1's data-gradient epilogue (ops.GradStash) instead of an
         # autograd accumulation pass over three full-size tensors
         stash = [] if (not self.downsample and inp.requires_grad and torch.is_grad_enabled()) else None
-        out = ops.instance_norm(self.conv1(inp, inp2, grad_stash=stash), None, True)
+        y1 = self.conv1(inp, inp2, grad_stash=stash)
+        c2 = self.conv2
+        # norm1's output feeds conv2 only: written 16-channel-blocked when conv2 runs on the halo kernel (ops.wants_b16)
+        out = ops.instance_norm(y1, None, True, out_b16=ops.wants_b16(c2.conv.weight, y1, c2.stride, c2.padding))
         out = self.conv2(out)
         if self.downsample:
             residual = ops.instance_norm(self.conv3(inp, inp2), None, False)
@@ -332,13 +334,7 @@ class UnetOutBlock(nn.Module):
 
 def _head(x, weight, bias):
     """Per-voxel linear to n_cls logits, computed with N padded to LOGIT_PAD; returns a [B, n_cls, D, H, W] view."""
-    n_cls = weight.shape[0]
-    if n_cls > LOGIT_PAD:
-        raise NotImplementedError(f"out_channels > {LOGIT_PAD} not supported by the logits/loss kernels")
-    w = F.pad(weight.reshape(n_cls, -1), (0, 0, 0, LOGIT_PAD - n_cls))
-    b = F.pad(bias, (0, LOGIT_PAD - n_cls))
-    out = ops.linear(x, w, b)  # [B, D, H, W, 16]
-    return out[..., :n_cls].permute(0, 4, 1, 2, 3)
+    return ops.head(x, weight, bias)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -443,6 +439,7 @@ class _VitBranch(_Base):
 
 class CTUNet(_VitBranch):
     """networks/hybrid_CTUNet.py:694-857."""
+    overlap_branches = True   # run the ResNet and the ViT encoder on two HIP streams (set False to serialise them)
 
     def __init__(self, in_channels: int, dim_conv_stem: int, out_channels: int, model_depth: int,
                  img_size: Tuple[int, int], frames: int, patch_frame: int, hidden_size: int = 768, num_depths: int = 12,
@@ -471,8 +468,24 @@ class CTUNet(_VitBranch):
         # milliseconds - would be the LAST gradients to become ready and its 350 MB all-reduce would sit exposed behind the
         # backward pass.  ResNet first: in backward the ViT branch finishes early and the long convnet backward, which
         # releases its gradients layer by layer down to the small stem, hides the communication (train.DataParallel).
-        res_enc1, res_enc2, res_enc3, res_enc4 = self.convnet(x)
-        vit_enc, vit_logits, vit_96x96 = self._vit_forward(x)
+        if self.overlap_branches:
+            # ... and they run CONCURRENTLY, on two HIP streams: the ViT trunk (864 tokens) and the small-volume stages of both
+            # branches are latency-bound launches that leave most of the 256 CUs idle; side by side they fill each other's
+            # gaps and the tails of the large convolutions.  Autograd replays every node on its forward stream, so the
+            # backward pass overlaps the same way.  (Workspaces are per stream, ops._wskey.)
+            main = torch.cuda.current_stream()
+            side = ops.side_stream(x.device)
+            side.wait_stream(main)      # (recorded before the convnet is queued: the side stream starts with it, not after it)
+            res_enc1, res_enc2, res_enc3, res_enc4 = self.convnet(x)
+            with torch.cuda.stream(side):
+                vit_enc, vit_logits, vit_96x96 = self._vit_forward(x)
+            main.wait_stream(side)
+            for t in (*vit_enc[1:4], vit_logits, vit_96x96):
+                t.record_stream(main)   # allocated in the side stream's pool, consumed on the main stream
+            x.record_stream(side)
+        else:
+            res_enc1, res_enc2, res_enc3, res_enc4 = self.convnet(x)
+            vit_enc, vit_logits, vit_96x96 = self._vit_forward(x)
         res_dec3 = self.res_decoder3(res_enc4, res_enc3, vit_enc[1])
         res_dec2 = self.res_decoder2(res_dec3, res_enc2, vit_enc[2])
         res_dec1 = self.res_decoder1(res_dec2, res_enc1, vit_enc[3])

@@ -128,7 +128,10 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         stash = [] if (self.downsample is None and x.requires_grad and torch.is_grad_enabled()) else None
-        out = ops.instance_norm(self.conv1(x, grad_stash=stash), None, True)
+        y1 = self.conv1(x, grad_stash=stash)
+        c2 = self.conv2
+        # gn1's output feeds conv2 only: written 16-channel-blocked when conv2 runs on the halo kernel (ops.wants_b16)
+        out = ops.instance_norm(y1, None, True, out_b16=ops.wants_b16(c2.conv.weight, y1, c2.stride, c2.padding))
         out = ops.instance_norm(self.conv2(out), None, True)
         out = self.conv3(out)
         if self.downsample is not None:

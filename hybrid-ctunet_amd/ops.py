@@ -20,6 +20,34 @@ from ._lib import AttnGeom, Epilogue, Geom, call, dcode, ptr, stream
 LRELU_SLOPE = 0.01
 
 # ---------------------------------------------------------------------------------------------------------------
+# side streams (CTUNet runs its two independent encoder branches on two HIP streams; autograd replays each node on the
+# stream its forward ran on).  Whoever consumes results on the main stream joins them first.
+# ---------------------------------------------------------------------------------------------------------------
+_side_streams = {}
+
+
+def side_stream(device, tag: str = "branch"):
+    key = (device, tag)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def side_streams(device):
+    return [st for (dev, _), st in _side_streams.items() if dev == device]
+
+
+def join_side_streams():
+    """Make torch's current stream wait for everything queued so far on the side streams (weight-gradient kernels write
+    straight into the flat gradient buffer from whichever stream their layer ran on; the optimizer / the all-reduce of the
+    last bucket must not start before them)."""
+    cur = torch.cuda.current_stream() if torch.cuda.is_available() else None
+    for (dev, _), st in _side_streams.items():
+        if cur is not None and cur.device == dev:
+            cur.wait_stream(st)
+
+# ---------------------------------------------------------------------------------------------------------------
 # packed-weight cache
 # ---------------------------------------------------------------------------------------------------------------
 _weights_epoch = 0
@@ -30,6 +58,26 @@ def bump_weights_epoch():
     """Call after parameters were modified by something torch's version counter cannot see (the fused AdamW)."""
     global _weights_epoch
     _weights_epoch += 1
+
+
+class _Built:
+    """Where and when a cached panel was produced: a consumer on another stream waits for the event once."""
+    __slots__ = ("event", "sid", "waited")
+
+    def __init__(self, device):
+        self.sid, self.event, self.waited = 0, None, None
+        if device.type == "cuda":
+            self.sid = stream()
+            self.event = torch.cuda.Event()
+            self.event.record()
+            self.waited = {self.sid}
+
+    def fence(self):
+        if self.event is not None:
+            sid = stream()
+            if sid not in self.waited:
+                torch.cuda.current_stream().wait_event(self.event)
+                self.waited.add(sid)
 
 
 def _packed(param: torch.Tensor, kind: str, dtype: torch.dtype, builder):
@@ -47,10 +95,11 @@ def _packed(param: torch.Tensor, kind: str, dtype: torch.dtype, builder):
     slot = ent[1]
     hit = slot.get((kind, dtype))
     if hit is not None and hit[0] == ver:
+        hit[2].fence()
         return hit[1]
     with torch.no_grad():
         t = builder()
-    slot[(kind, dtype)] = (ver, t)
+    slot[(kind, dtype)] = (ver, t, _Built(t.device))
     return t
 
 
@@ -117,8 +166,9 @@ def clear_grad_sinks():
 _sink_uses = {}
 
 
-def sink_expect(param):
-    if param is not None and param.requires_grad and torch.is_grad_enabled() and param.data_ptr() in _grad_sinks:
+def sink_expect(param, needed: bool = True):
+    """Called from an autograd.Function's forward (where grad mode is off: `needed` is ctx.needs_input_grad[i])."""
+    if needed and param is not None and param.data_ptr() in _grad_sinks:
         k = param.data_ptr()
         _sink_uses[k] = _sink_uses.get(k, 0) + 1
 
@@ -193,14 +243,22 @@ def _conv_splitk(M: int, N: int, K: int, taps: int) -> int:
     return max(1, min(its // 8, (255 + tiles) // tiles))
 
 
+def _wskey(device):
+    """Persistent workspaces are private to a (device, stream) pair: kernels of one stream run in order, so a workspace
+    handed back clean by one launch is clean for the next; two streams (the two encoder branches of CTUNet run on two,
+    see networks/hybrid_CTUNet.py) must never share one."""
+    return (device, stream()) if device.type == "cuda" else (device, 0)
+
+
 _SPLITK_WS = {}
 
 
 def _splitk_workspace(device, n):
     """Persistent fp32 split-K workspace (zero between calls: the finish kernel hands it back zeroed)."""
-    ws = _SPLITK_WS.get(device)
+    key = _wskey(device)
+    ws = _SPLITK_WS.get(key)
     if ws is None or ws.numel() < n:
-        ws = _SPLITK_WS[device] = torch.zeros(max(n, 1 << 22), dtype=torch.float32, device=device)
+        ws = _SPLITK_WS[key] = torch.zeros(max(n, 1 << 22), dtype=torch.float32, device=device)
     return ws
 
 
@@ -247,9 +305,10 @@ _TN_WS = {}
 def _tn_workspace(device):
     """Persistent scratch (16 Mi floats) for the two-stage reduction of small weight-gradient panels; contents are
     irrelevant between calls (every partial is written before it is read), single compute stream."""
-    ws = _TN_WS.get(device)
+    key = _wskey(device)
+    ws = _TN_WS.get(key)
     if ws is None:
-        ws = _TN_WS[device] = torch.empty(1 << 24, dtype=torch.float32, device=device)
+        ws = _TN_WS[key] = torch.empty(1 << 24, dtype=torch.float32, device=device)
     return ws
 
 
@@ -323,8 +382,8 @@ class LinearFn(torch.autograd.Function):
                 global _last_in_acc
                 _last_in_acc = acc
         ctx.save_for_backward(x, weight, pre, bias)
-        sink_expect(weight)
-        sink_expect(bias)
+        sink_expect(weight, ctx.needs_input_grad[1])
+        sink_expect(bias, ctx.needs_input_grad[2])
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         ctx.act = act
@@ -409,9 +468,11 @@ class ConvFn(torch.autograd.Function):
     Reference: get_conv_layer, networks/resnet.py:17-50 (3x3x3 s1/s2, 1x1x1 s2)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, stride, padding, grad_stash=None):
+    def forward(ctx, x1, x2, weight, stride, padding, grad_stash=None, x1_b16=False, link=None):
         _check_act(x1)
         ctx.grad_stash = grad_stash
+        ctx.x1_b16 = bool(x1_b16)
+        ctx.link = link
         B, D, H, W, C1 = x1.shape
         C2 = 0 if x2 is None else x2.shape[-1]
         N = weight.shape[0]
@@ -429,9 +490,15 @@ class ConvFn(torch.autograd.Function):
                 acc = _in_acc_take(x1.device, B * N * 2)
             ws = _tn_workspace(x1.device)
             call("ctu_conv3_halo", dcode(x1.dtype), ptr(x1), ptr(x2), ptr(wfr), ptr(out), None, B, D, H, W, C1, C2, N, 0,
-                 N, 0, ptr(acc[1]) if acc is not None else None, None, ptr(ws), ws.numel(), stream())
+                 N, 0, ptr(acc[1]) if acc is not None else None, None, ptr(ws), ws.numel(), int(ctx.x1_b16), stream())
             ctx.in_acc = acc
+            # the InstanceNorm that follows may hand this conv's data- and weight-gradient kernels their dY in the blocked
+            # layout (they are its only readers)
+            ctx.b16_grad_ok = B16_LAYOUT and x1.dtype == torch.bfloat16 and N % 32 == 0 and \
+                B * D * H * W * max(N, K) < (1 << 31)
         else:
+            if ctx.x1_b16:
+                raise RuntimeError("a CTU_LAYOUT_B16 tensor reached a convolution that is not on the 3x3x3 halo kernel")
             wf = _packed(weight, "conv_f", x1.dtype,
                          lambda: _pack(weight, (taps, N, K), (1, K * taps, taps), x1.dtype))
             g = _geom(B, (D, H, W), dout, C1, C2, N, k, stride, padding, 0)
@@ -440,10 +507,11 @@ class ConvFn(torch.autograd.Function):
             _igemm_nt(x1, x2, wf, out, g, _epi(N, splitk=sk, splitk_ws=_splitk_workspace(x1.device, M * N) if sk > 1 else None))
         ctx.save_for_backward(x1, x2, weight)
         if taps > 1:
-            sink_expect(weight)
+            sink_expect(weight, ctx.needs_input_grad[2])
         ctx.cfg = (stride, padding, k, dout)
+        global _last_in_acc, _last_b16_grad_ok
+        _last_b16_grad_ok = bool(getattr(ctx, "b16_grad_ok", False))
         if getattr(ctx, "in_acc", None) is not None:
-            global _last_in_acc
             _last_in_acc = ctx.in_acc
             ctx.in_acc = None
         return out
@@ -453,11 +521,15 @@ class ConvFn(torch.autograd.Function):
         x1, x2, weight = ctx.saved_tensors
         stride, padding, k, dout = ctx.cfg
         gy = gy.contiguous()
+        gy_b16 = ctx.link is not None and ctx.link.gy_b16   # dY written blocked by the InstanceNorm backward behind this conv
+        x1_b16 = ctx.x1_b16
         B, D, H, W, C1 = x1.shape
         C2 = 0 if x2 is None else x2.shape[-1]
         N, K = weight.shape[0], C1 + C2
         taps = k[0] * k[1] * k[2]
         g1 = g2 = gw = None
+        if (gy_b16 or x1_b16) and not (_halo_ok(k, stride, padding) and N % 32 == 0 and C1 % 32 == 0 and C2 % 32 == 0):
+            raise RuntimeError("CTU_LAYOUT_B16 operand outside the halo convolution kernels")
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
             g1 = torch.empty_like(x1)
             g2 = torch.empty_like(x2) if x2 is not None else None
@@ -471,7 +543,7 @@ class ConvFn(torch.autograd.Function):
                     if extra.shape != x1.shape or extra.dtype != x1.dtype or not extra.is_contiguous():
                         extra = extra.to(x1.dtype).contiguous().view_as(x1)
                 call("ctu_conv3_halo", dcode(x1.dtype), ptr(gy), None, ptr(wfr), ptr(g1), ptr(g2), B, D, H, W, N, 0, K,
-                     C1 if x2 is not None else 0, C1, C2, None, ptr(extra), ptr(ws), ws.numel(), stream())
+                     C1 if x2 is not None else 0, C1, C2, None, ptr(extra), ptr(ws), ws.numel(), int(gy_b16), stream())
             else:
                 # dX[v][c] = sum_t sum_n dY[(v + p - t)/s][n] W[n][c][t]  ->  panel [t][c][n]
                 wd = _packed(weight, "conv_d", x1.dtype,
@@ -491,7 +563,7 @@ class ConvFn(torch.autograd.Function):
                 panel = torch.zeros((taps, N, K), dtype=torch.float32, device=x1.device)
             if _halo_ok(k, stride, padding) and C1 % 32 == 0 and C2 % 32 == 0:
                 call("ctu_conv3_halo_wgrad", dcode(x1.dtype), ptr(gy), ptr(x1), ptr(x2), ptr(panel), B, D, H, W, C1, C2,
-                     N, stream())
+                     N, int(x1_b16), int(gy_b16), stream())
             else:
                 gq = _geom(B, (D, H, W), dout, C1, C2, N, k, stride, padding, 0)
                 _igemm_tn(gy, N, x1, x2, panel, gq)
@@ -505,7 +577,7 @@ class ConvFn(torch.autograd.Function):
                 permute3(panel, gw, (N, K, taps), (K, 1, N * K), (K * taps, taps, 1))
         if ctx.grad_stash:  # not consumed by a fused epilogue (generic path): add it here
             g1 = g1 + ctx.grad_stash.pop().to(g1.dtype)
-        return g1, g2, gw, None, None, None
+        return g1, g2, gw, None, None, None, None, None
 
 
 _PANEL_SCRATCH = {}
@@ -514,13 +586,42 @@ _PANEL_SCRATCH = {}
 def _panel_scratch(device, n):
     """Persistent fp32 scratch for multi-tap weight-gradient panels; zero between uses (permute3 accumulate=2 clears
     what it read), single compute stream."""
-    t = _PANEL_SCRATCH.get(device)
+    key = _wskey(device)
+    t = _PANEL_SCRATCH.get(key)
     if t is None or t.numel() < n:
-        t = _PANEL_SCRATCH[device] = torch.zeros(max(n, 27 * 512 * 512), dtype=torch.float32, device=device)
+        t = _PANEL_SCRATCH[key] = torch.zeros(max(n, 27 * 512 * 512), dtype=torch.float32, device=device)
     return t[:n]
 
 
 USE_HALO_CONV = True  # tests flip this to run the generic implicit GEMM on the same shapes
+
+# CTU_LAYOUT_B16 (include/ctunet_hip.h): the tensor between an InstanceNorm and the 3x3x3 halo convolution that is its only
+# consumer - forward (norm output -> conv input) and backward (norm input gradient -> the producing conv's dY) - is stored
+# as [C/16][voxels][16].  Same bytes, same shape attribute.  Forward: instance_norm(out_b16=True) marks its result
+# (`_ctu_b16`), conv3d reads the mark and raises if the convolution cannot run on the halo kernel.  Backward: the conv's
+# autograd node and the norm applied to its output share a _B16Link (set in the norm's forward, read in the conv's
+# backward) - the blocked gradient travels along exactly one graph edge.
+B16_LAYOUT = not os.environ.get("CTU_NO_B16")
+
+
+class _B16Link:
+    """Shared between a halo convolution's autograd node and the InstanceNorm applied to its output: the norm's forward
+    sets `gy_b16` when its backward will write that conv's dY in CTU_LAYOUT_B16; the conv's backward reads it."""
+    __slots__ = ("gy_b16",)
+
+    def __init__(self):
+        self.gy_b16 = False
+
+
+def wants_b16(conv_weight, x: torch.Tensor, stride, padding) -> bool:
+    """Should the InstanceNorm in front of this convolution write its output blocked?  (x: the norm's input = the conv's
+    future input, channels-last [B, D, H, W, C].)"""
+    if not (B16_LAYOUT and USE_HALO_CONV and x.dtype == torch.bfloat16 and x.dim() == 5):
+        return False
+    k = tuple(conv_weight.shape[2:])
+    C, N = x.shape[-1], conv_weight.shape[0]
+    return (_halo_ok(k, _t3(stride), _t3(padding)) and C % 32 == 0 and conv_weight.shape[1] == C and
+            x.numel() // C * max(C, N) < (1 << 31))
 
 
 def _halo_ok(k, stride, padding) -> bool:
@@ -556,11 +657,13 @@ def _packed_frag(param, kind, dtype, N, K, taps, sn, sc, st, flip):
     ver = (param._version, _weights_epoch, param.data_ptr(), tuple(param.shape))
     hit = ent[1].get((kind, dtype)) if ent is not None and ent[0]() is param else None
     if hit is not None and hit[0] == ver:
+        hit[2].fence()
         return hit[1]
     _repack_all(param.device)
     ent = _pack_cache.get(id(param))
     hit = ent[1].get((kind, dtype)) if ent is not None and ent[0]() is param else None
     if hit is not None and hit[0] == ver:
+        hit[2].fence()
         return hit[1]
     return _packed(param, kind, dtype, single)           # (not covered by the batch after all)
 
@@ -603,6 +706,7 @@ def _repack_all(device):
         table = torch.from_numpy(rows.view(np.uint8).reshape(-1)).to(device)
         tab = st["tables"][side] = (sig, [k for k, _, _ in live], table, buf, views, nblocks)
     call("ctu_pack_frag_batched", ptr(tab[2]), len(live), tab[5], stream())
+    built = _Built(device)   # one event for the whole batch
     for (key, prm, job), view in zip(live, tab[4]):
         ver = (prm._version, _weights_epoch, prm.data_ptr(), tuple(prm.shape))
         ent = _pack_cache.get(id(prm))
@@ -610,7 +714,7 @@ def _repack_all(device):
             pid = id(prm)
             ent = (weakref.ref(prm, lambda _r, pid=pid: _pack_cache.pop(pid, None)), {})
             _pack_cache[pid] = ent
-        ent[1][(key[1], key[2])] = (ver, view)
+        ent[1][(key[1], key[2])] = (ver, view, built)
 
 
 def _pack_frag(weight, N, K, taps, sn, sc, st, flip, dtype):
@@ -636,10 +740,16 @@ def _pack(weight, n, src_strides, dtype):
 def conv3d(x1, weight, stride=1, padding=0, x2=None, grad_stash=None):
     global _last_in_acc
     _last_in_acc = None
-    out = ConvFn.apply(x1, x2, weight, _t3(stride), _t3(padding), grad_stash)
+    global _last_b16_grad_ok
+    _last_b16_grad_ok = False
+    link = _B16Link()
+    out = ConvFn.apply(x1, x2, weight, _t3(stride), _t3(padding), grad_stash, bool(getattr(x1, "_ctu_b16", False)), link)
     if _last_in_acc is not None:
         out._ctu_in_acc = _last_in_acc  # instance_norm(out, ...) picks the statistics up instead of re-reading `out`
         _last_in_acc = None
+    if _last_b16_grad_ok:
+        out._ctu_b16_link = link        # instance_norm(out, ...) may write this conv's dY in CTU_LAYOUT_B16
+        _last_b16_grad_ok = False
     return out
 
 
@@ -652,10 +762,11 @@ _IN_ACC_RING = {}
 
 
 def _in_acc_take(device, n):
-    ring = _IN_ACC_RING.get(device)
+    key = _wskey(device)
+    ring = _IN_ACC_RING.get(key)
     if ring is None or ring[0][0][0].numel() < n:
         size = max(n, 1 << 13)
-        ring = _IN_ACC_RING[device] = [[[torch.zeros(size, dtype=torch.float64, device=device), False] for _ in range(4)], 0]
+        ring = _IN_ACC_RING[key] = [[[torch.zeros(size, dtype=torch.float64, device=device), False] for _ in range(4)], 0]
     slots, nxt = ring
     slot = slots[nxt]
     ring[1] = (nxt + 1) % len(slots)
@@ -807,7 +918,7 @@ class InstanceNormFn(torch.autograd.Function):
     (resnet.py:97-124,156-157,198; hybrid_CTUNet.py:84-104)."""
 
     @staticmethod
-    def forward(ctx, x, residual, act: bool):
+    def forward(ctx, x, residual, act: bool, out_b16: bool = False):
         _check_act(x)
         B, C = x.shape[0], x.shape[-1]
         S = x.numel() // (B * C)
@@ -823,7 +934,15 @@ class InstanceNormFn(torch.autograd.Function):
         else:
             acc = _in_workspace(x.device, B * C * 2)[0]  # zero on entry, handed back zeroed by ctu_in_stats
             call("ctu_in_stats", dc, ptr(x), B, S, C, ptr(acc), ptr(stats), stream())
-        call("ctu_in_apply", dc, ptr(x), ptr(stats), ptr(residual), ptr(y), B, S, C, int(act), stream())
+        if out_b16 and (residual is not None or x.dtype != torch.bfloat16 or C % 16):
+            raise RuntimeError("CTU_LAYOUT_B16 output: bf16, C % 16 == 0, no residual")
+        call("ctu_in_apply", dc, ptr(x), ptr(stats), ptr(residual), ptr(y), B, S, C, int(act), int(out_b16), stream())
+        # x is the output of a halo conv: its gradient has one reader, that conv's backward, which takes it blocked
+        link = getattr(x, "_ctu_b16_link", None)
+        ctx.dx_b16 = link is not None and x.dtype == torch.bfloat16 and C % 16 == 0 and ctx.needs_input_grad[0]
+        if ctx.dx_b16:
+            link.gy_b16 = True
+            x._ctu_b16_link = None   # one norm per conv output: a second consumer would read a blocked gradient sum
         ctx.has_res = residual is not None
         # without a residual sign(y) == sign(xhat): backward recomputes the LeakyReLU mask from x and needs no y
         ctx.save_for_backward(x, y if ctx.has_res else None, stats)
@@ -847,10 +966,10 @@ class InstanceNormFn(torch.autograd.Function):
         # Cache, is 2 % slower than one pass over the whole batch)
         call("ctu_in_bwd_reduce", dc, ptr(gy), ptr(x), ptr(y), ptr(stats), ptr(sums), B, S, C, ctx.act, stream())
         call("ctu_in_bwd_apply", dc, ptr(gy), ptr(x), ptr(y), ptr(stats), ptr(sums), ptr(gx), ptr(gres), B, S, C,
-             ctx.act, ptr(dirty), dirty_n, stream())
+             ctx.act, ptr(dirty), dirty_n, int(ctx.dx_b16), stream())
         ws[3] ^= 1
         ws[4] = B * C * 2
-        return gx, gres, None
+        return gx, gres, None, None
 
 
 _IN_WS = {}
@@ -859,16 +978,21 @@ _IN_WS = {}
 def _in_workspace(device, n):
     """Persistent fp64 InstanceNorm accumulators of one device (single compute stream): [fwd acc, bwd sums A, bwd sums B,
     index of the clean bwd buffer, dirty entries of the other].  The kernels keep them zero between uses."""
-    ws = _IN_WS.get(device)
+    key = _wskey(device)
+    ws = _IN_WS.get(key)
     if ws is None or ws[0].numel() < n:
         size = max(n, 1 << 15)
         ws = [torch.zeros(size, dtype=torch.float64, device=device) for _ in range(3)] + [0, 0]
-        _IN_WS[device] = ws
+        _IN_WS[key] = ws
     return ws
 
 
-def instance_norm(x, residual=None, act=False):
-    return InstanceNormFn.apply(x, residual, act)
+def instance_norm(x, residual=None, act=False, out_b16: bool = False):
+    """out_b16: write the result in CTU_LAYOUT_B16 - only when its one consumer is a 3x3x3 halo convolution (wants_b16)."""
+    y = InstanceNormFn.apply(x, residual, act, out_b16)
+    if out_b16:
+        y._ctu_b16 = True   # ops.conv3d reads the mark; nothing else may consume y
+    return y
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -884,8 +1008,8 @@ class LayerNormFn(torch.autograd.Function):
         mr = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
         call("ctu_layernorm_fwd", dcode(x.dtype), ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mr), rows, dim, stream())
         ctx.save_for_backward(x, gamma, mr, beta)
-        sink_expect(gamma)
-        sink_expect(beta)
+        sink_expect(gamma, ctx.needs_input_grad[1])
+        sink_expect(beta, ctx.needs_input_grad[2])
         return y
 
     @staticmethod
@@ -1155,6 +1279,133 @@ def patchify(x, p1, p2, p3):
     tok = torch.empty((B, (H // p1) * (W // p2) * (Fr // p3), p1 * p2 * p3), dtype=x.dtype, device=x.device)
     call("ctu_patchify", dcode(x.dtype), ptr(x), ptr(tok), B, H, W, Fr, p1, p2, p3, stream())
     return tok
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# classification heads: per-voxel Linear(C -> n_cls <= 16) + bias, logits computed into 16-column rows
+# ---------------------------------------------------------------------------------------------------------------
+LOGIT_PAD = 16
+_head_state = {}      # id(weight) -> {"ref", dtype -> [version key, w16 [16][K], wT16 [K][16]], "b16", "gw16", "gb16", built}
+_padded_grads = {}    # data_ptr of a [.., 16] gradient buffer whose pad columns are zero (train.DiceCEFn.backward) -> True
+
+
+def note_padded_grad(buf: torch.Tensor):
+    """The producer of a logits gradient (the fused DiceCE backward) announces a channels-last buffer with LOGIT_PAD
+    columns whose pad columns are written as zeros: HeadFn.backward then multiplies the buffer as it stands."""
+    if len(_padded_grads) > 64:   # announcements nobody collected (a loss on logits that are not a head's)
+        _padded_grads.clear()
+    _padded_grads[buf.data_ptr()] = True
+
+
+def _head_panels(weight, bias, dtype):
+    """Zero-padded panels of a head: W [16][K] (forward) and W^T [K][16] (data gradient) in the activation dtype, bias
+    fp32 [16].  The buffers persist (pad rows / columns stay zero for ever); after a parameter update only the 14 real
+    rows are rewritten: one cast and one permute launch per head and step, no fills."""
+    n_cls, K = weight.shape[0], weight[0].numel()
+    st = _head_state.get(id(weight))
+    if st is None or st["ref"]() is not weight:
+        wid = id(weight)
+        st = _head_state[wid] = {"ref": weakref.ref(weight, lambda _r, wid=wid: _head_state.pop(wid, None))}
+    ver = (weight._version, bias._version if bias is not None else -1, _weights_epoch, weight.data_ptr())
+    ent = st.get(dtype)
+    if ent is None:
+        dev = weight.device
+        ent = st[dtype] = [None, torch.zeros((LOGIT_PAD, K), dtype=dtype, device=dev),
+                           torch.zeros((K, LOGIT_PAD), dtype=dtype, device=dev),
+                           torch.zeros(LOGIT_PAD, dtype=torch.float32, device=dev), None]
+    if ent[0] != ver:
+        with torch.no_grad():
+            w = weight.detach().reshape(n_cls, K)
+            call("ctu_cast", ptr(w), dcode(torch.float32), ptr(ent[1]), dcode(dtype), n_cls * K, stream())
+            permute3(w, ent[2], (K, n_cls, 1), (1, K, 0), (LOGIT_PAD, 1, 0))
+            if bias is not None:
+                call("ctu_cast", ptr(bias.detach()), dcode(torch.float32), ptr(ent[3]), dcode(torch.float32), n_cls, stream())
+        ent[0] = ver
+        ent[4] = _Built(weight.device)
+    else:
+        ent[4].fence()
+    return ent[1], ent[2], ent[3]
+
+
+def _head_scratch(weight, K):
+    """Persistent zeroed fp32 [16][K] + [16] accumulators of a head's weight / bias gradient (direct-sink path)."""
+    st = _head_state[id(weight)]
+    sc = st.get("scratch")
+    if sc is None:
+        sc = st["scratch"] = (torch.zeros((LOGIT_PAD, K), dtype=torch.float32, device=weight.device),
+                              torch.zeros(LOGIT_PAD, dtype=torch.float32, device=weight.device))
+    return sc
+
+
+class HeadFn(torch.autograd.Function):
+    """UnetOutBlock (1x1x1 conv with bias, hybrid_CTUNet.py:781-783,810) / DecoderLinear.head (:679,685): logits
+    [B, D, H, W, 16] with the first n_cls columns meaningful, returned as the [B, n_cls, D, H, W] view the caller's loss
+    indexes.  Forward and backward stay in the padded layout: no slicing, padding or re-layout pass anywhere."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _check_act(x)
+        n_cls, K = weight.shape[0], weight[0].numel()
+        if n_cls > LOGIT_PAD:
+            raise NotImplementedError(f"out_channels > {LOGIT_PAD} not supported by the logits/loss kernels")
+        M = x.numel() // K
+        w16, _, b16 = _head_panels(weight, bias, x.dtype)
+        out = torch.empty((*x.shape[:-1], LOGIT_PAD), dtype=x.dtype, device=x.device)
+        _plain_gemm(x, w16, out, M, K, LOGIT_PAD, bias=b16 if bias is not None else None)
+        ctx.save_for_backward(x, weight, bias)
+        sink_expect(weight, ctx.needs_input_grad[1])
+        sink_expect(bias, bias is not None and ctx.needs_input_grad[2])
+        return out[..., :n_cls].permute(0, 4, 1, 2, 3)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, bias = ctx.saved_tensors
+        n_cls, K = weight.shape[0], weight[0].numel()
+        M = x.numel() // K
+        B, _, D, H, W = g.shape
+        st = g.stride()
+        padded = (g.dtype == x.dtype and st[1] == 1 and st[4] == LOGIT_PAD and st[3] == W * LOGIT_PAD and
+                  st[2] == H * W * LOGIT_PAD and st[0] == D * H * W * LOGIT_PAD and
+                  _padded_grads.pop(g.data_ptr(), None) is not None)
+        if padded:
+            g16 = torch.as_strided(g, (B, D, H, W, LOGIT_PAD), (st[0], st[2], st[3], st[4], 1))
+        else:  # a foreign gradient: re-lay it out (plumbing; the fused loss never takes this path)
+            g16 = torch.zeros((B, D, H, W, LOGIT_PAD), dtype=x.dtype, device=x.device)
+            g16[..., :n_cls] = g.permute(0, 2, 3, 4, 1)
+        _, wT16, _ = _head_panels(weight, bias, x.dtype)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _plain_gemm(g16, wT16, gx, M, LOGIT_PAD, K)            # dX = dY16 @ W16
+        want_gb = bias is not None and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_gb:
+            gw_buf, gw_done = _direct_grad(weight) if ctx.needs_input_grad[1] else (None, None)
+            gb_buf, gb_done = _direct_grad(bias) if want_gb else (None, None)
+            direct = (gw_buf is not None or not ctx.needs_input_grad[1]) and (gb_buf is not None or not want_gb)
+            if direct:
+                gw16, gb16 = _head_scratch(weight, K)              # zero on entry, handed back zeroed below
+            else:
+                gw16 = torch.zeros((LOGIT_PAD, K), dtype=torch.float32, device=x.device)
+                gb16 = torch.zeros(LOGIT_PAD, dtype=torch.float32, device=x.device)
+            if ctx.needs_input_grad[1]:
+                _igemm_tn(g16, LOGIT_PAD, x, None, gw16, _plain_geom(M, K, LOGIT_PAD), bias_grad=gb16 if want_gb else None)
+            else:
+                call("ctu_colsum", dcode(g16.dtype), ptr(g16), None, M, LOGIT_PAD, LOGIT_PAD, ptr(gb16), stream())
+            if direct:
+                if gw_buf is not None:
+                    permute3(gw16, gw_buf, (n_cls * K, 1, 1), (1, 0, 0), (1, 0, 0), accumulate=2)
+                    gw_done()
+                if gb_buf is not None:
+                    permute3(gb16, gb_buf, (n_cls, 1, 1), (1, 0, 0), (1, 0, 0), accumulate=2)
+                    gb_done()
+            else:
+                gw = gw16[:n_cls].view(weight.shape) if ctx.needs_input_grad[1] else None
+                gb = gb16[:n_cls] if want_gb else None
+        return gx, gw, gb
+
+
+def head(x, weight, bias):
+    return HeadFn.apply(x, weight, bias)
 
 
 def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

@@ -91,6 +91,8 @@ class DiceCEFn(torch.autograd.Function):
         call("ctu_dicece_bwd", dcode(buf.dtype), ptr(buf), ldl, ptr(tgt), ptr(i0), ptr(i1), ptr(i2), B, D, H, W, LD, LH,
              LW, n_cls, ptr(acc), nr, dr, weight, ptr(gscale), ptr(dl), stream())
         g = dl[..., :n_cls].permute(0, 4, 1, 2, 3)
+        if ldl == ops.LOGIT_PAD:
+            ops.note_padded_grad(dl)   # pad columns are zero: the head's backward multiplies the buffer as it stands
         if not padded:
             g = g.to(in_dtype)
         return g, None, None, None, None
@@ -299,6 +301,8 @@ class FusedAdamW:
         return self._static_skip
 
     def step(self):
+        if self.flat.flat.is_cuda:
+            ops.join_side_streams()   # weight gradients written from the ViT branch's stream
         self.step_count += 1
         skip = self._static_skip if self._static_skip is not None else self.flat.untouched_ranges()
         if len(skip) > 16:
@@ -398,6 +402,8 @@ class DataParallel(nn.Module):
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self._side.wait_event(ev)
+            for st in ops.side_streams(sl.device):   # members of this bucket may come from the other branch's stream
+                self._side.wait_stream(st)
             with torch.cuda.stream(self._side):
                 self._reduce_cuda(sl)
         else:
@@ -421,6 +427,8 @@ class DataParallel(nn.Module):
 
     def finish(self):
         """Call after backward, before the optimizer step."""
+        if self._is_cuda:
+            ops.join_side_streams()
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)  # buckets containing parameters that never produced a gradient

@@ -32,6 +32,15 @@ extern "C" {
 #define CTU_ERR_LAUNCH 2  /* hipGetLastError() after launch was not hipSuccess */
 
 typedef enum { CTU_F32 = 0, CTU_BF16 = 1 } ctu_dtype;
+/* Memory layout of a volume tensor [B][D][H][W][C].  CTU_LAYOUT_NDHWC: channels-last rows, element (voxel m, channel c)
+ * at m*C + c - the layout of every tensor unless stated.  CTU_LAYOUT_B16: 16-channel blocks outermost,
+ * [C/16][B*D*H*W][16], element at ((c >> 4) * voxels + m) * 16 + (c & 15).  It exists for ONE dataflow: the input of a
+ * 3x3x3 convolution that is the output of an InstanceNorm (+LeakyReLU) (resnet.py:106-113, hybrid_CTUNet.py:93-99) - and,
+ * backwards, the gradient an InstanceNorm backward hands to the convolution in front of it.  The halo convolution
+ * gathers its input 16 channels at a time: from channels-last rows that is 32 bytes out of every voxel's row (one cache
+ * line touched per voxel and pass), from B16 a halo row of 10 voxels is one 320-byte run.  Produced only by
+ * ctu_in_apply / ctu_in_bwd_apply, consumed only by ctu_conv3_halo / ctu_conv3_halo_wgrad (bf16). */
+typedef enum { CTU_LAYOUT_NDHWC = 0, CTU_LAYOUT_B16 = 1 } ctu_layout;
 typedef void* ctu_stream_t; /* hipStream_t */
 
 int ctu_abi_version(void);
@@ -141,15 +150,17 @@ int ctu_conv_cin1_wgrad(ctu_dtype dtype, const void* x, const void* dy, float* d
  * in a gradient that reached the same tensor through another branch (identity shortcut of a ResBlock).
  * ws (optional fp32 scratch, ws_floats entries, contents irrelevant): volumes of a few bricks (the 12x12x24 and
  * 6x6x12 stages) split their input channels over workgroups, keep fp32 partial outputs there and sum them in a
- * second pass (bf16, n_split == 0). */
+ * second pass (bf16, n_split == 0).
+ * x1_layout: ctu_layout of x1 (x2 is always channels-last). */
 int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, const void* wfrag, void* out, void* out2,
                    int32_t B, int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N, int32_t n_split,
                    int32_t ldc, int32_t ldc2, double* in_acc, const void* residual, float* ws, int64_t ws_floats,
-                   ctu_stream_t stream);
+                   int32_t x1_layout, ctu_stream_t stream);
 /* Weight gradient of the same convolution with the halo staged once per brick:
  * dw[27][N][C1+C2] += sum_v dy[v][n] * x[v + tap - 1][c]  (fp32 atomics into a zeroed panel). dy: [B][D][H][W][N]. */
 int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void* x1, const void* x2, float* dw, int32_t B,
-                         int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N, ctu_stream_t stream);
+                         int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N, int32_t x1_layout,
+                         int32_t dy_layout, ctu_stream_t stream);
 /* Pack fp32 weights W(n, c, tap) = src[n*sn + c*sc + tap*st] into MFMA-fragment order
  * dst[K/32][taps][2][ceil(N/32)][64 lanes][8] (zero padded), optionally with the tap order reversed (flip = 1). */
 int ctu_pack_frag(const float* src, void* dst, ctu_dtype dst_dtype, int32_t N, int32_t K, int32_t taps, int64_t sn,
@@ -190,18 +201,20 @@ int ctu_in_stats(ctu_dtype dtype, const void* x, int32_t B, int64_t S, int32_t C
 /* (mean, rstd) from UNSHIFTED fp64 sums (sum x, sum x^2) accumulated by a producer (ctu_conv3_halo in_acc); acc is
  * handed back zeroed. */
 int ctu_in_finalize(int32_t B, int64_t S, int32_t C, double* acc, float* stats, ctu_stream_t stream);
+/* y_layout: ctu_layout of y (CTU_LAYOUT_B16 when the one consumer of y is ctu_conv3_halo; y must not alias x then). */
 int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, const void* residual, void* y, int32_t B,
-                 int64_t S, int32_t C, int32_t act, ctu_stream_t stream);
+                 int64_t S, int32_t C, int32_t act, int32_t y_layout, ctu_stream_t stream);
 /* backward: g = dy * act'(y) (y may be NULL when no residual was added: then sign(y) == sign(xhat) and the third
  * input stream is skipped); sums[b][c] = (sum g, sum g*xhat), fp64, zero on entry;
  * dx = rstd*(g - s1/S - xhat*s2/S); dres = g when dres != NULL.  ctu_in_bwd_apply also zeroes clear_ws[0..clear_n)
  * (optional, must differ from sums): pass the sums buffer of the PREVIOUS call on the stream so two buffers can
- * alternate without a memset launch. */
+ * alternate without a memset launch.  dx_layout: ctu_layout of dx (CTU_LAYOUT_B16 when x is the output of a
+ * ctu_conv3_halo convolution, whose data- and weight-gradient kernels are the only readers of dx). */
 int ctu_in_bwd_reduce(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
                       double* sums, int32_t B, int64_t S, int32_t C, int32_t act, ctu_stream_t stream);
 int ctu_in_bwd_apply(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
                      const double* sums, void* dx, void* dres, int32_t B, int64_t S, int32_t C, int32_t act,
-                     double* clear_ws, int32_t clear_n, ctu_stream_t stream);
+                     double* clear_ws, int32_t clear_n, int32_t dx_layout, ctu_stream_t stream);
 
 /* K8 LayerNorm (eps 1e-5, affine) (vit.py:35,55,116,118; hybrid_CTUNet.py:456,518,630-631).
  * x,y: [rows][dim]; mean_rstd: fp32 [rows][2]; dgamma/dbeta: fp32 [dim], accumulated (atomics). */

@@ -351,7 +351,10 @@ def test_drop_in_protocol(H):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16), pytest.warns(UserWarning, match="bfloat16"):
         o16 = m(x[:1])                                   # the reference's default AMP dtype: accepted, fp16 logits back
     assert o16[0][0].dtype == torch.float16 and o16[1][1].dtype == torch.float16
-    assert torch.allclose(o16[0][0].float(), out[0][0][:1].float(), atol=2e-2, rtol=2e-2)
+    # same volume as sample 0 of the batch-4 pass (other kernel shapes: agreement up to bf16 noise, not bit-wise)
+    ref0 = out[0][0][:1].float()
+    assert (o16[0][0].float() - ref0).abs().max() <= 0.2 * ref0.abs().max()
+    assert (o16[1][0].float() - out[1][0][:1].float()).abs().max() <= 0.05 * out[1][0][:1].float().abs().max()
     with pytest.raises(RuntimeError):
         m.cpu()(x[:1].cpu())
 
@@ -529,6 +532,8 @@ def test_stagewise_bf16_drift_teacher_forced(H):
     for stage, rms, mx in rows:
         print(f"  {stage:38s} {rms:.3e}  {mx:.3e}")
     # gates: ~2x what a healthy bf16 stage measures on the MI355X (values recorded in DESIGN.md section 5)
-    limits = {"convnet.layer1": 0.08, "convnet.layer2": 0.08, "convnet.layer3": 0.12, "convnet.layer4": 0.05}
+    # measured (round 2, MI355X): stem 4.6e-3, layer1 2.8e-2 (8 bottlenecks), layer2 3.3e-2 (9), layer3 4.7e-2 (13), layer4 1.2e-2
+    # (3), fusion decoders 1.1e-2, res_decoder0 5.4e-3, ViT trunk 9.0e-3, window stages 4.5-8.1e-3, vit_decoder0 4.5e-3, heads 2.8e-3
+    limits = {"convnet.layer1": 0.06, "convnet.layer2": 0.07, "convnet.layer3": 0.10, "convnet.layer4": 0.03}
     for stage, rms, mx in rows:
-        assert rms <= limits.get(stage, 0.05), (stage, rms, mx)
+        assert rms <= limits.get(stage, 0.025), (stage, rms, mx)

@@ -585,3 +585,41 @@ def test_batched_fragment_packing_equals_single(ops):
     for ra, rb in zip(a, b):
         for ta, tb in zip(ra, rb):
             assert torch.equal(ta, tb)
+
+
+@pytest.mark.parametrize("case", [(2, 8, 16, 16, 32, 32), (1, 5, 9, 11, 64, 96), (2, 4, 8, 8, 128, 64)])
+def test_b16_layout_chain_equals_channels_last(ops, case):
+    """CTU_LAYOUT_B16 (the 16-channel-blocked tensor between an InstanceNorm and the 3x3x3 halo convolution behind it, and
+    between an InstanceNorm backward and the convolution in front of it) changes where bytes live, not what is computed:
+    conv1 -> IN+LReLU -> conv2 -> IN+LReLU with the layout on and off must give the same output, input gradient and
+    weight gradients (the only differences allowed: the arrival order of fp64 / fp32 atomics)."""
+    B, D, H, W, C, N = case
+    dtype = torch.bfloat16
+    x0 = rnd((B, D, H, W, C), 11).to(dtype).cuda()
+    w1 = torch.nn.Parameter(rnd((N, C, 3, 3, 3), 12, 1 / math.sqrt(27 * C)).cuda())
+    w2 = torch.nn.Parameter(rnd((N, N, 3, 3, 3), 13, 1 / math.sqrt(27 * N)).cuda())
+    gout = rnd((B, D, H, W, N), 14).to(dtype).cuda()
+
+    def run(b16):
+        ops.B16_LAYOUT = b16
+        try:
+            x = x0.clone().requires_grad_(True)
+            for w in (w1, w2):
+                w.grad = None
+            y1 = ops.conv3d(x, w1, 1, 1)
+            use = ops.wants_b16(w2, y1, 1, 1)
+            assert use == b16
+            a1 = ops.instance_norm(y1, None, True, out_b16=use)
+            y2 = ops.conv3d(a1, w2, 1, 1)
+            out = ops.instance_norm(y2, None, True)
+            out.backward(gout)
+            torch.cuda.synchronize()
+            return out.detach().float(), x.grad.float(), w1.grad.clone(), w2.grad.clone()
+        finally:
+            ops.B16_LAYOUT = True
+    ref = run(False)
+    got = run(True)
+    for name, a, b in zip(("out", "dx", "dw1", "dw2"), got, ref):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 1e-2 * scale, name
+        assert (a == b).float().mean().item() > 0.99, name

@@ -50,10 +50,10 @@ def _blocks():
     return {
         "resblock_same": lambda: O.ResBlock(16, 16, 3, 1),
         "resblock_proj": lambda: O.ResBlock(32, 16, 3, 1),
-        "resblock_in1": lambda: O.ResBlock(1, 16, 3, 1),
+        "resblock_in1": lambda: O.ResBlock(1, 64, 3, 1),
         "bottleneck_s2": lambda: O.Bottleneck(32, 16, (2, 2, 2), O._Downsample(32, 64, (2, 2, 2))),
         "bottleneck_id": lambda: O.Bottleneck(64, 16),
-        "stem": lambda: O.ConvLayer(1, 16, (7, 7, 7), (2, 2, 1)),
+        "stem": lambda: O.ConvLayer(1, 64, (7, 7, 7), (2, 2, 1)),
         "convt222": lambda: O.ConvLayer(32, 16, (2, 2, 2), (2, 2, 2), is_transposed=True),
         "convt221": lambda: O.ConvLayer(32, 16, (2, 2, 1), (2, 2, 1), is_transposed=True),
         "upcat": lambda: O.UpCatConvBlock(32, 16, 3, (2, 2, 2)),

@@ -13,6 +13,7 @@ from hybrid_ctunet_amd import ops  # noqa: E402
 from hybrid_ctunet_amd._lib import Geom, call, dcode, ptr, stream  # noqa: E402
 
 DT = torch.bfloat16
+LAYOUT = int(os.environ.get("KB_LAYOUT", "0"))  # 1: CTU_LAYOUT_B16 operands for the InstanceNorm / halo conv cases
 dev = "cuda"
 
 
@@ -92,7 +93,7 @@ def inorm(B, D, H, W, C, sets=3):
 
     def f_apply():
         i = nxt()
-        call("ctu_in_apply", dcode(DT), ptr(xs[i]), ptr(stats), None, ptr(ys[i]), B, S, C, 1, stream())
+        call("ctu_in_apply", dcode(DT), ptr(xs[i]), ptr(stats), None, ptr(ys[i]), B, S, C, 1, LAYOUT, stream())
 
     def f_stats():
         i = nxt()
@@ -105,7 +106,7 @@ def inorm(B, D, H, W, C, sets=3):
     def f_bapply():
         i = nxt()
         call("ctu_in_bwd_apply", dcode(DT), ptr(gs[i]), ptr(xs[i]), None, ptr(stats), ptr(sums), ptr(ys[i]), None, B, S, C, 1,
-             ptr(dirty), B * C * 2, stream())
+             ptr(dirty), B * C * 2, LAYOUT, stream())
     tag = f"{C}ch @{D}x{H}x{W} B{B}"
     report(f"in_apply       {tag}", timeit(f_apply), 0, 2 * nb)
     report(f"in_bwd_reduce  {tag}", timeit(f_red), 0, 2 * nb)
@@ -119,6 +120,8 @@ def halo(B, D, H, W, C, N, what):
     if what == "fwd":
         with torch.no_grad():
             ops.FUSE_IN_STATS = False
+            if LAYOUT:
+                x._ctu_b16 = True   # timing only: the same bytes read through the blocked addressing
             us = timeit(lambda: ops.conv3d(x, w, 1, 1))
             ops.FUSE_IN_STATS = True
         report(f"conv3_halo fwd {C}->{N} @{D}x{H}x{W} B{B}", us, flops, 2.0 * B * D * H * W * (C + N))
@@ -126,7 +129,7 @@ def halo(B, D, H, W, C, N, what):
         dy = torch.randn(B, D, H, W, N, device=dev, dtype=DT)
         panel = torch.zeros(27, N, C, device=dev)
         us = timeit(lambda: call("ctu_conv3_halo_wgrad", dcode(DT), ptr(dy), ptr(x), None, ptr(panel), B, D, H, W, C, 0, N,
-                                 stream()))
+                                 LAYOUT, LAYOUT, stream()))
         report(f"conv3_halo wgrad {C}->{N} @{D}x{H}x{W} B{B}", us, flops, 2.0 * B * D * H * W * (C + N))
 
 
