@@ -38,6 +38,36 @@ def side_streams(device):
     return [st for (dev, _), st in _side_streams.items() if dev == device]
 
 
+# Weight-gradient kernels of a layer depend only on (dY, X), not on the data gradient that the rest of the backward pass
+# waits for: with a training harness that owns the gradient storage (direct sinks) they are queued on a companion stream
+# of the layer's compute stream and overlap the data-gradient chain - the small-volume stages and the 864-token ViT
+# trunk are launch-latency bound, two kernels side by side fill what one leaves idle.  The optimizer joins the streams.
+WGRAD_STREAM = not os.environ.get("CTU_NO_WGRAD_STREAM")
+
+
+class _WgradSide:
+    def __init__(self, enabled, device, *tensors):
+        self.on = bool(enabled and WGRAD_STREAM and device.type == "cuda")
+        self.device, self.tensors = device, tensors
+
+    def __enter__(self):
+        if self.on:
+            cur = torch.cuda.current_stream()
+            ws = side_stream(self.device, ("wgrad", cur.cuda_stream))
+            ws.wait_stream(cur)                      # dY (and everything before it) is ordered in front of the side work
+            for t in self.tensors:
+                if t is not None:
+                    t.record_stream(ws)              # freed by the caller's scope while the side stream may still read it
+            self._cm = torch.cuda.stream(ws)
+            self._cm.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self._cm.__exit__(*exc)
+        return False
+
+
 def join_side_streams():
     """Make torch's current stream wait for everything queued so far on the side streams (weight-gradient kernels write
     straight into the flat gradient buffer from whichever stream their layer ran on; the optimizer / the all-reduce of the
@@ -420,16 +450,18 @@ class LinearFn(torch.autograd.Function):
         gb_buf, gb_done = _direct_grad(bias) if want_gb else (None, None)
         if want_gb and gb_buf is None:
             gb = gb_buf = torch.zeros(N, dtype=torch.float32, device=x.device)
-        if ctx.needs_input_grad[1]:
-            if gw_buf is None:
-                gw = gw_buf = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
-            _igemm_tn(g, N, x, None, gw_buf, _plain_geom(M, K, N), bias_grad=gb_buf if want_gb else None)
-        elif want_gb:
-            call("ctu_colsum", dcode(g.dtype), ptr(g), None, M, N, N, ptr(gb_buf), stream())
-        if gw_done is not None:
-            gw_done()
-        if gb_done is not None:
-            gb_done()
+        direct = (gw_done is not None or not ctx.needs_input_grad[1]) and (gb_done is not None or not want_gb)
+        with _WgradSide(direct, x.device, g, x):
+            if ctx.needs_input_grad[1]:
+                if gw_buf is None:
+                    gw = gw_buf = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+                _igemm_tn(g, N, x, None, gw_buf, _plain_geom(M, K, N), bias_grad=gb_buf if want_gb else None)
+            elif want_gb:
+                call("ctu_colsum", dcode(g.dtype), ptr(g), None, M, N, N, ptr(gb_buf), stream())
+            if gw_done is not None:
+                gw_done()
+            if gb_done is not None:
+                gb_done()
         return gx, gw, gb, gres, None, None, None
 
 
@@ -555,26 +587,27 @@ class ConvFn(torch.autograd.Function):
                                                      splitk_ws=_splitk_workspace(x1.device, Mi * K) if sk > 1 else None))
         if ctx.needs_input_grad[2]:
             gw_buf, gw_done = _direct_grad(weight) if taps > 1 else (None, None)
-            if gw_buf is not None:
-                # persistent zeroed scratch panel: the wgrad kernel accumulates into it, permute3 adds it into the
-                # parameter's gradient storage in the parameter's layout and hands the panel back zeroed
-                panel = _panel_scratch(x1.device, taps * N * K).view(taps, N, K)
-            else:
-                panel = torch.zeros((taps, N, K), dtype=torch.float32, device=x1.device)
-            if _halo_ok(k, stride, padding) and C1 % 32 == 0 and C2 % 32 == 0:
-                call("ctu_conv3_halo_wgrad", dcode(x1.dtype), ptr(gy), ptr(x1), ptr(x2), ptr(panel), B, D, H, W, C1, C2,
-                     N, int(x1_b16), int(gy_b16), stream())
-            else:
-                gq = _geom(B, (D, H, W), dout, C1, C2, N, k, stride, padding, 0)
-                _igemm_tn(gy, N, x1, x2, panel, gq)
-            if taps == 1:
-                gw = panel.view(weight.shape)
-            elif gw_buf is not None:
-                permute3(panel, gw_buf, (N, K, taps), (K, 1, N * K), (K * taps, taps, 1), accumulate=2)
-                gw_done()
-            else:
-                gw = torch.empty(weight.shape, dtype=torch.float32, device=x1.device)
-                permute3(panel, gw, (N, K, taps), (K, 1, N * K), (K * taps, taps, 1))
+            with _WgradSide(gw_buf is not None, x1.device, gy, x1, x2):
+                if gw_buf is not None:
+                    # persistent zeroed scratch panel: the wgrad kernel accumulates into it, permute3 adds it into the
+                    # parameter's gradient storage in the parameter's layout and hands the panel back zeroed
+                    panel = _panel_scratch(x1.device, taps * N * K).view(taps, N, K)
+                else:
+                    panel = torch.zeros((taps, N, K), dtype=torch.float32, device=x1.device)
+                if _halo_ok(k, stride, padding) and C1 % 32 == 0 and C2 % 32 == 0:
+                    call("ctu_conv3_halo_wgrad", dcode(x1.dtype), ptr(gy), ptr(x1), ptr(x2), ptr(panel), B, D, H, W, C1, C2,
+                         N, int(x1_b16), int(gy_b16), stream())
+                else:
+                    gq = _geom(B, (D, H, W), dout, C1, C2, N, k, stride, padding, 0)
+                    _igemm_tn(gy, N, x1, x2, panel, gq)
+                if taps == 1:
+                    gw = panel.view(weight.shape)
+                elif gw_buf is not None:
+                    permute3(panel, gw_buf, (N, K, taps), (K, 1, N * K), (K * taps, taps, 1), accumulate=2)
+                    gw_done()
+                else:
+                    gw = torch.empty(weight.shape, dtype=torch.float32, device=x1.device)
+                    permute3(panel, gw, (N, K, taps), (K, 1, N * K), (K * taps, taps, 1))
         if ctx.grad_stash:  # not consumed by a fused epilogue (generic path): add it here
             g1 = g1 + ctx.grad_stash.pop().to(g1.dtype)
         return g1, g2, gw, None, None, None, None, None

@@ -596,8 +596,8 @@ def test_b16_layout_chain_equals_channels_last(ops, case):
     B, D, H, W, C, N = case
     dtype = torch.bfloat16
     x0 = rnd((B, D, H, W, C), 11).to(dtype).cuda()
-    w1 = torch.nn.Parameter(rnd((N, C, 3, 3, 3), 12, 1 / math.sqrt(27 * C)).cuda())
-    w2 = torch.nn.Parameter(rnd((N, N, 3, 3, 3), 13, 1 / math.sqrt(27 * N)).cuda())
+    w1 = torch.nn.Parameter(rnd((N, C, 3, 3, 3), 12, 1 / math.sqrt(27 * C)).float().cuda())
+    w2 = torch.nn.Parameter(rnd((N, N, 3, 3, 3), 13, 1 / math.sqrt(27 * N)).float().cuda())
     gout = rnd((B, D, H, W, N), 14).to(dtype).cuda()
 
     def run(b16):
