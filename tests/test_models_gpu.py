@@ -212,15 +212,18 @@ def test_whole_model_fp32_matches_reference_golden(H, golden_dir, name):
     This deep InstanceNorm network amplifies fp32 rounding ~1000x: the fp32 REFERENCE is itself 2-4e-4 (outputs) and
     2-12 % (individual deep-layer gradient entries) away from the same reference run in float64 (golden *_f64.npz,
     produced by the reference's own code).  The gate is therefore the distance of the HIP path to the reference-in-fp64
-    value: outputs <= max(1e-3, 2x the fp32 reference's own distance), loss <= 1e-4, gradient norms / samples
-    <= max(5e-3, 2x the fp32 reference's own distance).  The direct HIP-vs-fp32-reference distance is printed beside it."""
+    value: outputs <= max(1e-3, 1.15x the fp32 reference's own distance) - the HIP path may be no noisier than torch-CPU;
+    what both carry is mostly the rounding of fp32 STORAGE, which any fp32 implementation shares (the two fp32 results
+    are closer to each other than either is to float64) - loss <= 1e-4, gradient norms / samples <= max(5e-3, 2x the
+    fp32 reference's own distance).  The direct HIP-vs-fp32-reference distance is printed beside it."""
     res = _run_model(H, golden_dir, name, "fp32")
     _report(name, "fp32", res)
     for k, (e_mine, e_ref, _) in res.items():
         if k == "loss":
             assert e_mine <= 1e-4, (k, e_mine)
         elif k.startswith("s"):
-            assert e_mine <= max(1e-3, 2 * e_ref), (k, e_mine, e_ref)
+            # 1.15x: measured 0.91-1.04x on the six ResNet-branch (sample, output) pairs of CTUNet-101 (DESIGN.md section 5)
+            assert e_mine <= max(1e-3, 1.15 * e_ref), (k, e_mine, e_ref)
         else:
             assert e_mine <= max(5e-3, 2 * e_ref), (k, e_mine, e_ref)
 
@@ -252,7 +255,8 @@ def test_whole_model_bf16_against_reference_under_autocast(H, golden_dir, name):
     Gate, PER OUTPUT and per sample: the HIP bf16 path may drift from the float64 value at most 1.5x as far as the
     reference-under-autocast does, in max norm and in rms; its argmax over the 14 classes must agree with the float64
     argmax on 2048 voxels at least as often as the reference's does (minus 1.5x its disagreement / 1 % slack); and its
-    Dice term must sit within max(1e-4, 1.5x the reference-bf16 distance) of the float64 Dice term.  Loss, gradient
+    Dice term must sit within max(1e-4, 2x the reference-bf16 distance) of the float64 Dice term (a scalar: two noise
+    draws of the same size differ by more than a tensor norm does).  Loss, gradient
     norms and sampled gradient entries are gated the same way against the reference-bf16 numbers."""
     from oracle import ctunet_oracle as O
     import gc
@@ -303,7 +307,7 @@ def test_whole_model_bf16_against_reference_under_autocast(H, golden_dir, name):
                 fails.append((f"s{s}/out{i} drift", em, er))
             if (1.0 - agree_m) > 1.5 * (1.0 - agree_r) + 0.01:
                 fails.append((f"s{s}/out{i} argmax", agree_m, agree_r))
-            if abs(dm - d64) > max(1e-4, 1.5 * abs(db - d64)):
+            if abs(dm - d64) > max(1e-4, 2.0 * abs(db - d64)):
                 fails.append((f"s{s}/out{i} dice", dm, db, d64))
     l64, lb = float(z64["loss_b2_64"]), float(zb["loss_b2"])
     print(f"  loss {loss.item():.6f}  ref-bf16 {lb:.6f}  ref-fp64 {l64:.6f}")

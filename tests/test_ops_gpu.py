@@ -621,5 +621,8 @@ def test_b16_layout_chain_equals_channels_last(ops, case):
     got = run(True)
     for name, a, b in zip(("out", "dx", "dw1", "dw2"), got, ref):
         scale = b.abs().max().item()
-        assert (a - b).abs().max().item() <= 1e-2 * scale, name
-        assert (a == b).float().mean().item() > 0.99, name
+        if name.startswith("dw"):   # fp32 atomics into the weight-gradient panel arrive in any order
+            assert (a - b).abs().max().item() <= 2e-3 * scale, name
+        else:
+            assert (a - b).abs().max().item() <= 1e-2 * scale, name
+            assert (a == b).float().mean().item() > 0.99, name
