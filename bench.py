@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=32.0)
+    ap.add_argument("--serial", action="store_true",
+                    help="one HIP stream (no branch / weight-gradient overlap): per-kernel profiles without co-running kernels")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -194,6 +196,16 @@ def main():
     x, y = synthetic_batch(a.batch, seed=1000 + rank)
     x, y = x.to(dev), y.to(dev)
     use_bf16 = a.precision == "bf16"
+    from hybrid_ctunet_amd import ops as _ops
+
+    def set_serial(flag):
+        """Serial = every kernel on one stream.  The timed region overlaps the two encoder branches and the weight-gradient
+        kernels on companion streams; the per-kernel roofline figures are taken with the overlap off, so a launch's HIP
+        events bracket that kernel alone."""
+        _ops.WGRAD_STREAM = not flag
+        if hasattr(model, "overlap_branches"):
+            model.overlap_branches = not flag
+    set_serial(a.serial)
 
     def step():
         opt.zero_grad()
@@ -229,6 +241,10 @@ def main():
     final_loss = loss.item()
 
     roofline = None
+    if not a.no_roofline:
+        set_serial(True)
+        step()   # (workspaces of the single-stream schedule are created outside the instrumented steps)
+        torch.cuda.synchronize()
     if not a.no_roofline and rank != 0:
         for _ in range(2):  # the instrumented steps below contain the gradient all-reduce: every rank takes part
             step()
@@ -253,7 +269,8 @@ def main():
                     "launches_per_step": s[dom]["launches"] // 2,
                     "avg_launch_ms": round(s[dom]["ms"] / s[dom]["launches"], 4),
                     "igemm_ms_per_step": tot,
-                    "note": "HIP events around every implicit-GEMM launch over 2 instrumented steps after the timed region"}
+                    "note": "HIP events around every implicit-GEMM launch over 2 instrumented single-stream steps after the "
+                            "timed region (the timed steps overlap kernels on several streams)"}
     if world > 1:
         dist.barrier()
 

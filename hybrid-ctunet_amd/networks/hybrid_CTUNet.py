@@ -159,12 +159,19 @@ class Up_2Fusion_Block(nn.Module):
         self.up_addconv_block1 = ResBlock(spatial_dims, out_channels, out_channels, kernel_size, 1, norm_name)
         self.up_addconv_block2 = ResBlock(spatial_dims, out_channels, out_channels, kernel_size, 1, norm_name)
 
+    def skip_path(self, skip_conv, skip_vit):
+        """First half of forward (hybrid_CTUNet.py:333-334): depends on the two encoders only, not on the decoder below."""
+        return self.up_addconv_block1(self.pixelweight_attention1(skip_conv, skip_vit))
+
+    def main_path(self, inp, skip):
+        """Second half (hybrid_CTUNet.py:336-340)."""
+        out = self.transp_conv(inp)
+        return self.up_addconv_block2(self.pixelweight_attention2(out, skip))
+
     def forward(self, inp, skip_conv=None, skip_vit=None):
         if skip_vit is None:
             raise NotImplementedError("the reference's forward requires skip_vit (skip is undefined otherwise)")
-        skip = self.up_addconv_block1(self.pixelweight_attention1(skip_conv, skip_vit))
-        out = self.transp_conv(inp)
-        return self.up_addconv_block2(self.pixelweight_attention2(out, skip))
+        return self.main_path(inp, self.skip_path(skip_conv, skip_vit))
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -427,13 +434,18 @@ class _VitBranch(_Base):
         """hybrid_CTUNet.py:812-815: tokens (h w f) -> volume; channels-last makes it a pure view."""
         return tokens.view(tokens.shape[0], *self.feat_size, self.hidden_size)
 
+    def _vit_pyramid(self, x):
+        """ViT trunk + window-attention pyramid (hybrid_CTUNet.py:821,824): [768@6.6.12, 512@12.12.24, ..., 64@96^3]."""
+        return self.vit_encoder(self.proj_feat(self.vit(x[..., 0])))
+
+    def _vit_heads(self, x, vit_enc):
+        """vit_encoder0 / vit_decoder0 and the two ViT-branch heads (hybrid_CTUNet.py:822,831-835)."""
+        vit_out = self.vit_decoder0(vit_enc[4], self.vit_encoder0(x))
+        return self.vit_out(vit_out), self.decoder_linear_96x96(vit_enc[4])
+
     def _vit_forward(self, x):
-        vit_features = self.vit(x[..., 0])
-        vit_enc0 = self.vit_encoder0(x)
-        vit_enc = self.vit_encoder(self.proj_feat(vit_features))
-        vit_out = self.vit_decoder0(vit_enc[4], vit_enc0)
-        vit_logits = self.vit_out(vit_out)
-        vit_96 = self.decoder_linear_96x96(vit_enc[4])
+        vit_enc = self._vit_pyramid(x)
+        vit_logits, vit_96 = self._vit_heads(x, vit_enc)
         return vit_enc, vit_logits, vit_96
 
 
@@ -468,6 +480,7 @@ class CTUNet(_VitBranch):
         # milliseconds - would be the LAST gradients to become ready and its 350 MB all-reduce would sit exposed behind the
         # backward pass.  ResNet first: in backward the ViT branch finishes early and the long convnet backward, which
         # releases its gradients layer by layer down to the small stem, hides the communication (train.DataParallel).
+        join_side = False
         if self.overlap_branches:
             # ... and they run CONCURRENTLY, on two HIP streams: the ViT trunk (864 tokens) and the small-volume stages of both
             # branches are latency-bound launches that leave most of the 256 CUs idle; side by side they fill each other's
@@ -477,22 +490,49 @@ class CTUNet(_VitBranch):
             side = ops.side_stream(x.device)
             side.wait_stream(main)      # (recorded before the convnet is queued: the side stream starts with it, not after it)
             res_enc1, res_enc2, res_enc3, res_enc4 = self.convnet(x)
+            feats_ready = torch.cuda.Event()
+            feats_ready.record(main)
             with torch.cuda.stream(side):
-                vit_enc, vit_logits, vit_96x96 = self._vit_forward(x)
-            main.wait_stream(side)
-            for t in (*vit_enc[1:4], vit_logits, vit_96x96):
-                t.record_stream(main)   # allocated in the side stream's pool, consumed on the main stream
+                vit_enc = self._vit_pyramid(x)
+                # The skip halves of the three fusion decoders (cross-weight fusion of the two encoders' features + a ResBlock,
+                # hybrid_CTUNet.py:333-334) need the encoders only: they leave the decoder chain res_decoder3 -> 2 -> 1 and run
+                # here, beside it - half of the decoders' work (res_decoder1 is the largest block of the model) off the
+                # critical path, forward and backward.  The chain waits for each skip tensor where it needs it.
+                side.wait_event(feats_ready)
+                skips, skip_ready = [], []
+                for d, e, v in ((self.res_decoder3, res_enc3, vit_enc[1]), (self.res_decoder2, res_enc2, vit_enc[2]),
+                                (self.res_decoder1, res_enc1, vit_enc[3])):
+                    e.record_stream(side)
+                    t = d.skip_path(e, v)
+                    t.record_stream(main)   # allocated in the side stream's pool, consumed on the main stream
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    skips.append(t)
+                    skip_ready.append(ev)
+                vit_logits, vit_96x96 = self._vit_heads(x, vit_enc)   # needed by the loss only
+                for t in (vit_logits, vit_96x96):
+                    t.record_stream(main)
             x.record_stream(side)
+            res_dec = res_enc4
+            decs = []
+            for d, t, ev in zip((self.res_decoder3, self.res_decoder2, self.res_decoder1), skips, skip_ready):
+                main.wait_event(ev)
+                res_dec = d.main_path(res_dec, t)
+                decs.append(res_dec)
+            res_dec3, res_dec2, res_dec1 = decs
+            join_side = True
         else:
             res_enc1, res_enc2, res_enc3, res_enc4 = self.convnet(x)
             vit_enc, vit_logits, vit_96x96 = self._vit_forward(x)
-        res_dec3 = self.res_decoder3(res_enc4, res_enc3, vit_enc[1])
-        res_dec2 = self.res_decoder2(res_dec3, res_enc2, vit_enc[2])
-        res_dec1 = self.res_decoder1(res_dec2, res_enc1, vit_enc[3])
+            res_dec3 = self.res_decoder3(res_enc4, res_enc3, vit_enc[1])
+            res_dec2 = self.res_decoder2(res_dec3, res_enc2, vit_enc[2])
+            res_dec1 = self.res_decoder1(res_dec2, res_enc1, vit_enc[3])
         res_out = self.res_decoder0(res_dec1)
         res_logits = self.res_out(res_out)
         res_logits_48x48 = self.res_out_48x48(res_dec1)
         res_logits_24x24 = self.res_out_24x24(res_dec2)
+        if join_side:
+            torch.cuda.current_stream().wait_stream(ops.side_stream(x.device))   # the ViT-branch logits
         return self._outputs(((res_logits, res_logits_48x48, res_logits_24x24), (vit_logits, vit_96x96)))
 
 
