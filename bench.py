@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=32.0)
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying one HIP graph")
     ap.add_argument("--serial", action="store_true",
                     help="one HIP stream (no branch / weight-gradient overlap): per-kernel profiles without co-running kernels")
     a = ap.parse_args()
@@ -191,7 +192,8 @@ def main():
     order = H.gradient_ready_order(model)
     flat = H.FlatParams(order)
     dp = H.DataParallel(model, flat=flat, bucket_mb=a.bucket_mb) if world > 1 else None
-    opt = H.FusedAdamW(None, lr=1e-4, weight_decay=1e-5, flat=flat)
+    use_graph = world == 1 and not a.no_graph and not a.serial
+    opt = H.FusedAdamW(None, lr=1e-4, weight_decay=1e-5, flat=flat, capturable=use_graph)
     loss_fn = H.LOSSES[a.model]
     x, y = synthetic_batch(a.batch, seed=1000 + rank)
     x, y = x.to(dev), y.to(dev)
@@ -218,10 +220,24 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(a.warmup):
+    for _ in range(max(a.warmup, 1) if use_graph else a.warmup):
         loss = step()
-    if a.warmup > 0:
+    if a.warmup > 0 or use_graph:
         opt.freeze_skip_ranges()
+    eager_step, graph_note = step, "eager"
+    if use_graph:
+        # The whole step as one HIP graph (train.GraphedStep): same kernels, same streams, no per-launch host work.  If the
+        # capture is refused the run continues eagerly and says so.
+        try:
+            graphed = H.GraphedStep(step, opt)
+            for _ in range(2):
+                graphed()
+            torch.cuda.synchronize()
+            step, graph_note = graphed, "hip-graph replay"
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); continuing eagerly", file=sys.stderr, flush=True)
+            graph_note = f"eager (graph capture failed: {type(e).__name__})"
+            torch.cuda.synchronize()
 
     def fence():
         if world > 1:
@@ -241,6 +257,7 @@ def main():
     final_loss = loss.item()
 
     roofline = None
+    step = eager_step
     if not a.no_roofline:
         set_serial(True)
         step()   # (workspaces of the single-stream schedule are created outside the instrumented steps)
@@ -287,7 +304,8 @@ def main():
             "config": {"workload": f"{a.model} d101 pf8, per-GPU batch {a.batch} x 1x96x96x96, fwd + DiceCE "
                                    f"(deep supervision, on-device targets) + bwd + fused AdamW"
                                    + (" + RCCL bucketed grad all-reduce" if world > 1 else ""),
-                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "params_M": round(n_params / 1e6, 2),
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "launch": graph_note,
+                       "params_M": round(n_params / 1e6, 2),
                        "final_loss": round(final_loss, 5)},
             "whole_path_tflops_per_gpu": round(whole_path, 2),
             "whole_path_frac_of_mfma_peak": round(whole_path / PEAK_BF16_TFLOPS, 4),

@@ -9,13 +9,13 @@ Nothing here falls back to eager PyTorch or to the CPU: the kernels live in csrc
 ``__graft_entry__.build()``), and every op raises if that library or a HIP device is missing.
 """
 from .networks.hybrid_CTUNet import CTUNet, CUNet, TUNet  # noqa: F401
-from .train import (DataParallel, FlatParams, FusedAdamW, LOSSES, ctunet_loss, cunet_loss, dice_ce_loss,  # noqa: F401
+from .train import (DataParallel, FlatParams, FusedAdamW, GraphedStep, LOSSES, ctunet_loss, cunet_loss, dice_ce_loss,  # noqa: F401
                     gradient_ready_order, tunet_loss)
 from .inference import dice_per_organ, hybrid_complement, sliding_window_inference  # noqa: F401
 from .checkpoint import load_checkpoint, save_checkpoint  # noqa: F401
 from .synthetic import synthetic_batch  # noqa: F401
 
-__all__ = ["CTUNet", "CUNet", "TUNet", "DataParallel", "FlatParams", "FusedAdamW", "LOSSES", "ctunet_loss",
+__all__ = ["CTUNet", "CUNet", "TUNet", "DataParallel", "FlatParams", "FusedAdamW", "GraphedStep", "LOSSES", "ctunet_loss",
            "cunet_loss", "tunet_loss", "dice_ce_loss", "gradient_ready_order", "sliding_window_inference",
            "hybrid_complement", "dice_per_organ", "load_checkpoint", "save_checkpoint", "synthetic_batch"]
 

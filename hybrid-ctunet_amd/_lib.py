@@ -80,7 +80,8 @@ _SIGS = {
     "ctu_dicece_fwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp] + [_i32] * 8 + [_vp, _vp],
     "ctu_dicece_finalize": [_vp, _i32, _i32, _i64, _f32, _f32, _f32, _vp, _vp],
     "ctu_dicece_bwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp] + [_i32] * 8 + [_vp, _f32, _f32, _f32, _vp, _vp, _vp],
-    "ctu_adamw": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, C.POINTER(_i64), _i32, _vp],
+    "ctu_adamw": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, C.POINTER(_i64), _i32, _vp, _vp],
+    "ctu_adamw_tick": [_vp, _f32, _f32, _vp],
     "ctu_cast": [_vp, _i32, _vp, _i32, _i64, _vp],
     "ctu_sw_accumulate": [_i32, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp] + [_i32] * 11 + [_vp],
     "ctu_sw_normalize": [_vp, _vp, _i32, _i32, _i64, _vp],

@@ -245,9 +245,14 @@ struct SkipRanges {
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, bf16* __restrict__ mirror,
                                                     const int64_t n,
-                                                    const float lr, const float b1, const float b2, const float eps,
-                                                    const float wd, const float inv_bc1, const float inv_sqrt_bc2,
-                                                    const SkipRanges skip) {
+                                                    float lr, const float b1, const float b2, const float eps,
+                                                    const float wd, float inv_bc1, float inv_sqrt_bc2,
+                                                    const SkipRanges skip, const float* __restrict__ hyper) {
+  if (hyper) {  // device-resident learning rate and bias corrections (ctu_adamw_tick): graph-replay safe
+    lr = hyper[0];
+    inv_bc1 = hyper[2];
+    inv_sqrt_bc2 = hyper[3];
+  }
   for (int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i4 < n; i4 += (int64_t)gridDim.x * 256 * 4) {
     bool skipped = false;
     for (int k = 0; k < skip.n; ++k) skipped = skipped || (i4 + 3 >= skip.r[k][0] && i4 < skip.r[k][1]);
@@ -290,10 +295,28 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// hyper (device, 4 x 32 bit): [0] lr (float), [1] step count (int32), [2] 1 / (1 - beta1^step), [3] 1 / sqrt(1 - beta2^step).
+// One thread advances the step and refreshes the two bias corrections: a captured HIP graph of a training step replays
+// with the right step number, and the learning rate is a device word the host may rewrite between replays.
+__global__ void adamw_tick_kernel(float* __restrict__ hyper, const float b1, const float b2) {
+  const int step = __float_as_int(hyper[1]) + 1;
+  hyper[1] = __int_as_float(step);
+  const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+  hyper[2] = (float)(1.0 / bc1);
+  hyper[3] = (float)(1.0 / sqrt(bc2));
+}
+
+extern "C" int ctu_adamw_tick(float* hyper_dev, float beta1, float beta2, ctu_stream_t stream) {
+  CTU_REQUIRE(hyper_dev, "adamw_tick: null pointer");
+  hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper_dev, beta1, beta2);
+  return ctu_check_launch("adamw_tick");
+}
+
 extern "C" int ctu_adamw(float* p, const float* g, float* m, float* v, void* mirror_bf16, int64_t n, float lr, float beta1, float beta2,
                          float eps, float weight_decay, int32_t step, const int64_t* skip_host, int32_t n_skip,
-                         ctu_stream_t stream) {
-  CTU_REQUIRE(p && g && m && v && n > 0 && step > 0, "adamw: bad args");
+                         const float* hyper_dev, ctu_stream_t stream) {
+  CTU_REQUIRE(p && g && m && v && n > 0 && (step > 0 || hyper_dev), "adamw: bad args");
+  if (hyper_dev) step = 1;  // (lr and the bias corrections come from the device words)
   CTU_REQUIRE(n_skip >= 0 && n_skip <= 16 && (n_skip == 0 || skip_host), "adamw: at most 16 skip ranges");
   CTU_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
               "adamw: buffers must be 16-byte aligned");
@@ -302,6 +325,6 @@ extern "C" int ctu_adamw(float* p, const float* g, float* m, float* v, void* mir
   for (int k = 0; k < n_skip; ++k) { sk.r[k][0] = skip_host[2 * k]; sk.r[k][1] = skip_host[2 * k + 1]; }
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     reinterpret_cast<bf16*>(mirror_bf16), n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), sk);
+                     reinterpret_cast<bf16*>(mirror_bf16), n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), sk, hyper_dev);
   return ctu_check_launch("adamw");
 }

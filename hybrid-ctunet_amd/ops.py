@@ -24,10 +24,19 @@ LRELU_SLOPE = 0.01
 # stream its forward ran on).  Whoever consumes results on the main stream joins them first.
 # ---------------------------------------------------------------------------------------------------------------
 _side_streams = {}
+_stream_epoch = 0   # bumped by new_stream_epoch(): a HIP-graph capture gets side streams (and thereby workspaces) of its own
 
 
-def side_stream(device, tag: str = "branch"):
-    key = (device, tag)
+def new_stream_epoch():
+    """Fresh side streams from now on.  A graph capture must not share per-stream workspaces with eager steps (their
+    state at the end of the captured step has to equal their state at its start: workspaces created INSIDE the capture are
+    re-zeroed by every replay), and streams used before must not be joined into the capture."""
+    global _stream_epoch
+    _stream_epoch += 1
+
+
+def side_stream(device, tag="branch"):
+    key = (device, tag, _stream_epoch)
     st = _side_streams.get(key)
     if st is None:
         st = _side_streams[key] = torch.cuda.Stream(device=device)
@@ -35,7 +44,7 @@ def side_stream(device, tag: str = "branch"):
 
 
 def side_streams(device):
-    return [st for (dev, _), st in _side_streams.items() if dev == device]
+    return [st for (dev, _, ep), st in _side_streams.items() if dev == device and ep == _stream_epoch]
 
 
 # Weight-gradient kernels of a layer depend only on (dY, X), not on the data gradient that the rest of the backward pass
@@ -73,8 +82,8 @@ def join_side_streams():
     straight into the flat gradient buffer from whichever stream their layer ran on; the optimizer / the all-reduce of the
     last bucket must not start before them)."""
     cur = torch.cuda.current_stream() if torch.cuda.is_available() else None
-    for (dev, _), st in _side_streams.items():
-        if cur is not None and cur.device == dev:
+    for (dev, _, ep), st in _side_streams.items():
+        if cur is not None and cur.device == dev and ep == _stream_epoch:
             cur.wait_stream(st)
 
 # ---------------------------------------------------------------------------------------------------------------

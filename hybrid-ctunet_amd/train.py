@@ -246,7 +246,11 @@ class FusedAdamW:
     buffers.  Parameters whose gradient was never produced in this step (7 ResBlock.conv3 tensors in CTUNet,
     SURVEY.md section 8a row D) are skipped exactly like torch skips `grad is None`."""
 
-    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, flat: Optional[FlatParams] = None):
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, flat: Optional[FlatParams] = None,
+                 capturable: bool = False):
+        """capturable: keep the learning rate, the step count and the bias corrections in four device words (advanced by
+        a one-thread kernel in front of the update), so that step() can be captured into a HIP graph and replayed
+        (GraphedStep); change the learning rate with set_lr()."""
         if flat is None:
             params = list(params)
             flat = FlatParams.of(params) or FlatParams(params)   # e.g. the one DataParallel(model) built
@@ -262,6 +266,22 @@ class FusedAdamW:
             if self.flat.flat.is_cuda else None
         self._mirror_stamp = None
         self.sync_mirror()
+        self.capturable = bool(capturable) and self.flat.flat.is_cuda
+        self.hyper = None
+        if self.capturable:
+            self.hyper = torch.zeros(4, dtype=torch.float32, device=self.flat.flat.device)
+            self.hyper[0] = lr
+
+    def set_lr(self, lr: float):
+        self.lr = self.param_groups[0]["lr"] = float(lr)
+        if self.hyper is not None:
+            self.hyper[0:1].fill_(float(lr))
+
+    def device_step_count(self) -> int:
+        """Steps taken, read back from the device in capturable mode (replayed graphs advance it without the host)."""
+        if self.hyper is None:
+            return self.step_count
+        return int(self.hyper[1:2].view(torch.int32).item())
 
     def sync_mirror(self):
         """Full fp32 -> bf16 refresh + (re)registration of the per-parameter views; needed only after the parameters
@@ -280,7 +300,7 @@ class FusedAdamW:
     def state_dict(self):
         """Flat optimizer state (for checkpoint.save_checkpoint): step count, hyper-parameters and the two moment buffers
         in FlatParams order together with the parameter shapes that define that order."""
-        return {"step": self.step_count, "param_groups": [dict(g) for g in self.param_groups],
+        return {"step": self.device_step_count(), "param_groups": [dict(g) for g in self.param_groups],
                 "shapes": [tuple(p.shape) for p in self.flat.params], "offsets": list(self.flat.offsets),
                 "exp_avg": self.m.detach().cpu(), "exp_avg_sq": self.v.detach().cpu()}
 
@@ -288,6 +308,8 @@ class FusedAdamW:
         if [tuple(s) for s in sd["shapes"]] != [tuple(p.shape) for p in self.flat.params]:
             raise ValueError("optimizer state was saved for a different parameter order / model")
         self.step_count = int(sd["step"])
+        if self.hyper is not None:
+            self.hyper[1:2].view(torch.int32).fill_(self.step_count)
         self.param_groups = [dict(g) for g in sd["param_groups"]]
         g0 = self.param_groups[0]
         self.lr, self.betas, self.eps, self.weight_decay = g0["lr"], tuple(g0["betas"]), g0["eps"], g0["weight_decay"]
@@ -312,11 +334,47 @@ class FusedAdamW:
             arr[2 * k], arr[2 * k + 1] = a, b
         f = self.flat
         lr = self.param_groups[0]["lr"]
+        if self.hyper is not None:
+            call("ctu_adamw_tick", ptr(self.hyper), self.betas[0], self.betas[1], stream())
         call("ctu_adamw", ptr(f.flat), ptr(f.grad), ptr(self.m), ptr(self.v), ptr(self.mirror), f.total, lr, self.betas[0],
-             self.betas[1], self.eps, self.weight_decay, self.step_count, arr, len(skip), stream())
+             self.betas[1], self.eps, self.weight_decay, self.step_count, arr, len(skip), ptr(self.hyper), stream())
         ops.bump_weights_epoch()
         if self.mirror is not None and self._mirror_stamp != (ops.mirror_generation(), tuple(p._version for p in f.params)):
             self.sync_mirror()  # someone else wrote parameters since the last sync (grad-less ones would stay stale)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# whole-step HIP graph
+# ---------------------------------------------------------------------------------------------------------------
+class GraphedStep:
+    """One training step - zero grads, forward, loss, backward, optimizer - captured into ONE HIP graph and replayed.
+
+    A step is ~2 300 kernel launches on three to five streams; enqueued from Python it costs the host ~40 ms, and wherever
+    the launching thread is busy with one stream the others starve.  The replayed graph hands the device the whole
+    dependency DAG at once.  Requirements (checked where possible): static input tensors (copy new batches into them),
+    FusedAdamW(capturable=True) with frozen skip ranges (one eager step first: freeze_skip_ranges()), no host
+    synchronisation inside `fn`.  `fn` returns the loss tensor (static as well: read it after replay).
+
+    Workspaces: capture runs on fresh streams (ops.new_stream_epoch), so every per-stream workspace is created - and
+    zero-filled - inside the graph; each replay therefore starts from the state the capture started from."""
+
+    def __init__(self, fn, optimizer: Optional["FusedAdamW"] = None):
+        if optimizer is not None:
+            if not optimizer.capturable:
+                raise ValueError("GraphedStep needs FusedAdamW(capturable=True)")
+            if optimizer._static_skip is None:
+                raise ValueError("run one eager step and call optimizer.freeze_skip_ranges() before capturing")
+        self.fn = fn
+        torch.cuda.synchronize()
+        ops.new_stream_epoch()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = fn()
+        torch.cuda.synchronize()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.out
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -297,10 +297,15 @@ int ctu_dicece_bwd(ctu_dtype dtype, const void* logits, int32_t ldl, const float
 /* K15 fused AdamW over one flat fp32 buffer (torch.optim.AdamW semantics, main_CTUNet.py:192-193).
  * skip: up to 16 [begin,end) element ranges left untouched (parameters whose .grad is None this step,
  * trainer_CTUNet.py:88-89 + torch's "skip if grad is None").  mirror_bf16 (optional, bf16 [n]): receives the updated
- * parameters rounded to bf16 - the GEMM kernels then read layer weights from it and no per-step cast pass exists. */
+ * parameters rounded to bf16 - the GEMM kernels then read layer weights from it and no per-step cast pass exists.
+ * hyper_dev (optional, device, 4 x 32 bit: lr, step count as int32, 1/(1-beta1^step), 1/sqrt(1-beta2^step)): when given, lr
+ * and the bias corrections are read from it instead of the arguments and `step` is ignored; ctu_adamw_tick advances the
+ * step count and refreshes the corrections on the device - a captured HIP graph of the training step then replays
+ * correctly, and the host changes the learning rate by rewriting hyper_dev[0]. */
 int ctu_adamw(float* p, const float* g, float* m, float* v, void* mirror_bf16, int64_t n, float lr, float beta1, float beta2,
               float eps, float weight_decay, int32_t step, const int64_t* skip_host, int32_t n_skip,
-              ctu_stream_t stream);
+              const float* hyper_dev, ctu_stream_t stream);
+int ctu_adamw_tick(float* hyper_dev, float beta1, float beta2, ctu_stream_t stream);
 /* ---- inference-side callers of forward ----------------------------------------------------
  * Sliding-window accumulation (trainer_CTUNet.py:538-548, trainer_CUNet.py:386-392): for one window whose prediction
  * element (c,d,h,w) is logits[c*sc + d*sd + h*sh + w*sw] (dtype fp32 or bf16, any strides - the models return

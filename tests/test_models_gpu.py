@@ -541,3 +541,46 @@ def test_stagewise_bf16_drift_teacher_forced(H):
     limits = {"convnet.layer1": 0.06, "convnet.layer2": 0.07, "convnet.layer3": 0.10, "convnet.layer4": 0.03}
     for stage, rms, mx in rows:
         assert rms <= limits.get(stage, 0.025), (stage, rms, mx)
+
+
+@pytest.mark.parametrize("kind", ["ctunet", "cunet"])
+def test_graphed_step_matches_eager(H, kind):
+    """train.GraphedStep: the whole training step (zero grads, forward under autocast(bf16), DiceCE, backward, fused AdamW
+    with device-resident step count) captured into one HIP graph must walk the same trajectory as the eager step: same
+    losses over four steps (capture itself executes step 2), same step count on the device."""
+    from oracle.ctunet_oracle import synthetic_batch
+    x, y = synthetic_batch(1, seed=1000)
+    x, y = x.cuda(), y.cuda()
+    losses = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(0)
+        m = H.build_model(kind, model_depth=50, **({"num_depths": 2} if kind == "ctunet" else {})).cuda()
+        flat = H.FlatParams(H.gradient_ready_order(m))
+        opt = H.FusedAdamW(None, lr=1e-3, weight_decay=1e-5, flat=flat, capturable=True)
+
+        def step():
+            opt.zero_grad()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = H.LOSSES[kind](m(x), y)
+            loss.backward()
+            opt.step()
+            return loss
+        out = [float(step())]
+        opt.freeze_skip_ranges()
+        if mode == "graph":
+            g = H.GraphedStep(step, opt)
+            out.append(float(g.out))          # the capture ran step 2
+            for _ in range(2):
+                out.append(float(g()))
+        else:
+            for _ in range(3):
+                out.append(float(step()))
+        assert opt.device_step_count() == 4
+        losses[mode] = out
+        del m, flat, opt
+        torch.cuda.synchronize()
+    print(f"\n[{kind}] eager {losses['eager']}\n[{kind}] graph {losses['graph']}")
+    assert abs(losses["eager"][0] - losses["graph"][0]) <= 1e-5 * abs(losses["eager"][0])
+    for a, b in zip(losses["eager"][1:], losses["graph"][1:]):
+        assert abs(a - b) <= 5e-3 * abs(a), losses
+    assert losses["graph"][3] != losses["graph"][2]   # replays really advance the parameters

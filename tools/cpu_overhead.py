@@ -5,7 +5,7 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hybrid_ctunet_amd as H
-from oracle.ctunet_oracle import synthetic_batch
+from hybrid_ctunet_amd.synthetic import synthetic_batch
 
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)

@@ -2,7 +2,7 @@ import sys, os, collections
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 import hybrid_ctunet_amd as H
-from oracle.ctunet_oracle import synthetic_batch
+from hybrid_ctunet_amd.synthetic import synthetic_batch
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = H.build_model("ctunet").to(dev)
