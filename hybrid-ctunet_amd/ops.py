@@ -24,27 +24,30 @@ LRELU_SLOPE = 0.01
 # stream its forward ran on).  Whoever consumes results on the main stream joins them first.
 # ---------------------------------------------------------------------------------------------------------------
 _side_streams = {}
-_stream_epoch = 0   # bumped by new_stream_epoch(): a HIP-graph capture gets side streams (and thereby workspaces) of its own
+_used_side = set()   # keys of side streams handed out since the last join_side_streams()
+_ws_epoch = 0        # bumped by new_workspace_epoch(): a HIP-graph capture gets per-stream workspaces of its own
 
 
-def new_stream_epoch():
-    """Fresh side streams from now on.  A graph capture must not share per-stream workspaces with eager steps (their
-    state at the end of the captured step has to equal their state at its start: workspaces created INSIDE the capture are
-    re-zeroed by every replay), and streams used before must not be joined into the capture."""
-    global _stream_epoch
-    _stream_epoch += 1
+def new_workspace_epoch():
+    """Fresh per-stream workspaces from now on.  A graph capture must not share them with eager steps: their state at the
+    end of the captured step has to equal their state at its start, and workspaces created INSIDE the capture are
+    zero-filled by every replay."""
+    global _ws_epoch
+    _ws_epoch += 1
 
 
 def side_stream(device, tag="branch"):
-    key = (device, tag, _stream_epoch)
+    key = (device, tag)
     st = _side_streams.get(key)
     if st is None:
         st = _side_streams[key] = torch.cuda.Stream(device=device)
+    _used_side.add(key)
     return st
 
 
 def side_streams(device):
-    return [st for (dev, _, ep), st in _side_streams.items() if dev == device and ep == _stream_epoch]
+    """Side streams that carried work since the last join."""
+    return [_side_streams[k] for k in _used_side if k[0] == device]
 
 
 # Weight-gradient kernels of a layer depend only on (dY, X), not on the data gradient that the rest of the backward pass
@@ -81,10 +84,13 @@ def join_side_streams():
     """Make torch's current stream wait for everything queued so far on the side streams (weight-gradient kernels write
     straight into the flat gradient buffer from whichever stream their layer ran on; the optimizer / the all-reduce of the
     last bucket must not start before them)."""
-    cur = torch.cuda.current_stream() if torch.cuda.is_available() else None
-    for (dev, _, ep), st in _side_streams.items():
-        if cur is not None and cur.device == dev and ep == _stream_epoch:
-            cur.wait_stream(st)
+    if not torch.cuda.is_available():
+        return
+    cur = torch.cuda.current_stream()
+    for key in list(_used_side):
+        if key[0] == cur.device:
+            cur.wait_stream(_side_streams[key])
+            _used_side.discard(key)
 
 # ---------------------------------------------------------------------------------------------------------------
 # packed-weight cache
@@ -286,7 +292,7 @@ def _wskey(device):
     """Persistent workspaces are private to a (device, stream) pair: kernels of one stream run in order, so a workspace
     handed back clean by one launch is clean for the next; two streams (the two encoder branches of CTUNet run on two,
     see networks/hybrid_CTUNet.py) must never share one."""
-    return (device, stream()) if device.type == "cuda" else (device, 0)
+    return (device, stream(), _ws_epoch) if device.type == "cuda" else (device, 0, 0)
 
 
 _SPLITK_WS = {}
@@ -730,23 +736,25 @@ def _repack_all(device):
         for key, prm, job in live:
             offs.append(total_bytes)
             total_bytes += (job[2] * (2 if key[2] == torch.bfloat16 else 4) + 255) // 256 * 256
-        buf = torch.empty(total_bytes, dtype=torch.uint8, device=device)
-        rows = np.zeros((len(live), 10), dtype=np.int64)    # 80-byte ctu_pack_job records
-        views = []
-        nblocks = 0
-        for r, ((key, prm, job), off) in enumerate(zip(live, offs)):
-            N, K, taps, sn, sc, stt, flip = job[1]
-            nbytes = job[2] * (2 if key[2] == torch.bfloat16 else 4)
-            view = buf[off:off + nbytes].view(key[2])
-            views.append(view)
-            rows[r, 0] = prm.data_ptr()
-            rows[r, 1] = view.data_ptr()
-            rows[r, 2:7] = (sn, sc, stt, job[2], nblocks)
-            nblocks += max(1, min(2048, (job[2] + 2047) // 2048))   # ~8 elements per thread, at most 2048 workgroups a job
-            i32 = np.array([N, K, taps, flip, (N + 31) // 32, dcode(key[2])], dtype=np.int32)
-            rows[r, 7:10] = i32.view(np.int64)
-        table = torch.from_numpy(rows.view(np.uint8).reshape(-1)).to(device)
-        tab = st["tables"][side] = (sig, [k for k, _, _ in live], table, buf, views, nblocks)
+        for sd in (side, 1 - side):   # both sides now: a later capture of the step finds its table on the device
+            buf = torch.empty(total_bytes, dtype=torch.uint8, device=device)
+            rows = np.zeros((len(live), 10), dtype=np.int64)    # 80-byte ctu_pack_job records
+            views = []
+            nblocks = 0
+            for r, ((key, prm, job), off) in enumerate(zip(live, offs)):
+                N, K, taps, sn, sc, stt, flip = job[1]
+                nbytes = job[2] * (2 if key[2] == torch.bfloat16 else 4)
+                view = buf[off:off + nbytes].view(key[2])
+                views.append(view)
+                rows[r, 0] = prm.data_ptr()
+                rows[r, 1] = view.data_ptr()
+                rows[r, 2:7] = (sn, sc, stt, job[2], nblocks)
+                nblocks += max(1, min(2048, (job[2] + 2047) // 2048))   # ~8 elements per thread, at most 2048 workgroups a job
+                i32 = np.array([N, K, taps, flip, (N + 31) // 32, dcode(key[2])], dtype=np.int32)
+                rows[r, 7:10] = i32.view(np.int64)
+            table = torch.from_numpy(rows.view(np.uint8).reshape(-1)).to(device)
+            st["tables"][sd] = (sig, [k for k, _, _ in live], table, buf, views, nblocks)
+        tab = st["tables"][side]
     call("ctu_pack_frag_batched", ptr(tab[2]), len(live), tab[5], stream())
     built = _Built(device)   # one event for the whole batch
     for (key, prm, job), view in zip(live, tab[4]):

@@ -566,12 +566,11 @@ def test_graphed_step_matches_eager(H, kind):
             opt.step()
             return loss
         out = [float(step())]
-        opt.freeze_skip_ranges()
         if mode == "graph":
-            g = H.GraphedStep(step, opt)
-            out.append(float(g.out))          # the capture ran step 2
-            for _ in range(2):
-                out.append(float(g()))
+            g = H.GraphedStep(step, opt, warmup=1)   # step 2 eagerly on the capture stream; capturing executes nothing
+            out.append(None)
+            out.append(float(g()))                   # step 3
+            out.append(float(g()))                   # step 4
         else:
             for _ in range(3):
                 out.append(float(step()))
@@ -581,6 +580,6 @@ def test_graphed_step_matches_eager(H, kind):
         torch.cuda.synchronize()
     print(f"\n[{kind}] eager {losses['eager']}\n[{kind}] graph {losses['graph']}")
     assert abs(losses["eager"][0] - losses["graph"][0]) <= 1e-5 * abs(losses["eager"][0])
-    for a, b in zip(losses["eager"][1:], losses["graph"][1:]):
+    for a, b in zip(losses["eager"][2:], losses["graph"][2:]):
         assert abs(a - b) <= 5e-3 * abs(a), losses
-    assert losses["graph"][3] != losses["graph"][2]   # replays really advance the parameters
+    assert losses["graph"][3] != losses["graph"][2]   # the replay really advanced the parameters
