@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=32.0)
+    ap.add_argument("--no-stage-graphs", action="store_true",
+                    help="enqueue the small-volume stages kernel by kernel instead of replaying their HIP graphs")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (train.GraphedStep).  Off by default: on ROCm 7.2 the graph executor "
                          "serialises the captured streams (58 ms / step against 49 ms enqueued eagerly on four streams)")
@@ -227,6 +229,12 @@ def main():
     if a.warmup > 0 or use_graph:
         opt.freeze_skip_ranges()
     eager_step, graph_note = step, "eager"
+    if not a.no_stage_graphs and not a.serial and use_bf16:
+        # the launch-latency-bound stages (ResNet layer3 / layer4, ViT trunk, first window stages) as HIP graphs
+        stages = H.graph_stages(model, x, flat=flat)
+        graph_note = f"eager, {len(stages)} small stages replayed from HIP graphs"
+        for _ in range(2):
+            loss = step()
     if use_graph:
         # The whole step as one HIP graph (train.GraphedStep): same kernels, same streams, no per-launch host work.  If the
         # capture is refused the run continues eagerly and says so.

@@ -14,6 +14,7 @@ from .train import (DataParallel, FlatParams, FusedAdamW, GraphedStep, LOSSES, c
 from .inference import dice_per_organ, hybrid_complement, sliding_window_inference  # noqa: F401
 from .checkpoint import load_checkpoint, save_checkpoint  # noqa: F401
 from .synthetic import synthetic_batch  # noqa: F401
+from .graphs import graph_stages  # noqa: F401
 
 __all__ = ["CTUNet", "CUNet", "TUNet", "DataParallel", "FlatParams", "FusedAdamW", "GraphedStep", "LOSSES", "ctunet_loss",
            "cunet_loss", "tunet_loss", "dice_ce_loss", "gradient_ready_order", "sliding_window_inference",

@@ -294,22 +294,38 @@ class UpAttentionBlock(nn.Module):
                 )
             self.layers.append(nn.Sequential(block))
 
+    @staticmethod
+    def _run_stage(blk, ind, x):
+        if ind <= 2:
+            x = blk[1](x, part=1)   # block windows + residual
+            x = blk[2](x)           # FF + residual
+            x = blk[5](x, part=2)   # grid windows + residual
+            x = blk[6](x)
+            return blk[8](x)
+        x = blk[1](x)
+        x = blk[2](x)
+        return blk[4](x)
+
+    def stage_runner(self, ind):
+        """Stage `ind` as a Module with forward(x) (detached from the model tree), for graphs.graph_stages."""
+        return _StageRunner(self.layers[ind][0], ind)
+
     def forward(self, x):
         features = [x]
         for ind, stage in enumerate(self.layers):
-            blk = stage[0]
-            if ind <= 2:
-                x = blk[1](x, part=1)   # block windows + residual
-                x = blk[2](x)           # FF + residual
-                x = blk[5](x, part=2)   # grid windows + residual
-                x = blk[6](x)
-                x = blk[8](x)
-            else:
-                x = blk[1](x)
-                x = blk[2](x)
-                x = blk[4](x)
+            graphed = getattr(self, f"_graphed_stage_{ind}", None)   # graphs.graph_stages
+            x = graphed(x) if graphed is not None else self._run_stage(stage[0], ind, x)
             features.append(x)
         return features
+
+
+class _StageRunner(nn.Module):
+    def __init__(self, blk, ind):
+        super().__init__()
+        self.blk, self.ind = blk, ind
+
+    def forward(self, x):
+        return UpAttentionBlock._run_stage(self.blk, self.ind, x)
 
 
 class DecoderLinear(nn.Module):

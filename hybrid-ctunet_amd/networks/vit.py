@@ -127,6 +127,9 @@ class ViT(nn.Module):
         x = ops.layer_norm(x, e[3].weight, e[3].bias)
         x = ops.add_bcast(x, self.pos_embedding)
         x = ops.dropout(x, self.dropout.p, self.training)
+        graphed = getattr(self, "_graphed_transformer", None)   # graphs.graph_stages: the 12 blocks as two graph launches
+        if graphed is not None:
+            return graphed(x)
         for blk in self.transformer:
             x = blk(x)
         return x

@@ -59,7 +59,7 @@ WGRAD_STREAM = not os.environ.get("CTU_NO_WGRAD_STREAM")
 
 class _WgradSide:
     def __init__(self, enabled, device, *tensors):
-        self.on = bool(enabled and WGRAD_STREAM and device.type == "cuda")
+        self.on = bool(enabled and WGRAD_STREAM and device.type == "cuda" and not torch.cuda.is_current_stream_capturing())
         self.device, self.tensors = device, tensors
 
     def __enter__(self):
@@ -128,7 +128,9 @@ class _Built:
 def _packed(param: torch.Tensor, kind: str, dtype: torch.dtype, builder):
     """Packed panel of a parameter, rebuilt when the parameter changes.  Only nn.Parameter objects are cached (keyed
     by object identity, weakly): temporaries could alias a freed tensor's address."""
-    if not isinstance(param, torch.nn.Parameter):
+    if not isinstance(param, torch.nn.Parameter) or (param.is_cuda and torch.cuda.is_current_stream_capturing()):
+        # (inside a graph capture the packing kernel must be part of the graph: a replay runs no Python, and a panel cached
+        # now would be read stale after the next optimizer step)
         with torch.no_grad():
             return builder()
     ver = (param._version, _weights_epoch, param.data_ptr(), tuple(param.shape))
@@ -693,7 +695,8 @@ def _frag_numel(N, K, taps):
 def _packed_frag(param, kind, dtype, N, K, taps, sn, sc, st, flip):
     """Fragment panel of a conv weight (cached per parameter like _packed; batched repacking, see above)."""
     single = lambda: _pack_frag(param, N, K, taps, sn, sc, st, flip, dtype)  # noqa: E731
-    if not (BATCH_PACK and isinstance(param, torch.nn.Parameter) and param.is_contiguous() and param.dtype == torch.float32):
+    if not (BATCH_PACK and isinstance(param, torch.nn.Parameter) and param.is_contiguous() and param.dtype == torch.float32) \
+            or (param.is_cuda and torch.cuda.is_current_stream_capturing()):
         return _packed(param, kind, dtype, single)
     key = (id(param), kind, dtype)
     job = _frag_jobs.get(key)
@@ -1363,7 +1366,7 @@ def _head_panels(weight, bias, dtype):
         ent = st[dtype] = [None, torch.zeros((LOGIT_PAD, K), dtype=dtype, device=dev),
                            torch.zeros((K, LOGIT_PAD), dtype=dtype, device=dev),
                            torch.zeros(LOGIT_PAD, dtype=torch.float32, device=dev), None]
-    if ent[0] != ver:
+    if ent[0] != ver or torch.cuda.is_current_stream_capturing():
         with torch.no_grad():
             w = weight.detach().reshape(n_cls, K)
             call("ctu_cast", ptr(w), dcode(torch.float32), ptr(ent[1]), dcode(dtype), n_cls * K, stream())

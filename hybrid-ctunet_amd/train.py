@@ -165,6 +165,7 @@ class FlatParams:
                 p.data = self.flat[o:o + p.numel()].view(p.shape)
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
         self.touched = [False] * len(self.params)
+        self.always_touched = set()   # parameters whose gradients are written by replayed graphs (graphs.graph_stages)
         self.listeners = []  # callables(i): "the gradient of parameter i is complete for this backward"
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
         me = weakref.ref(self)
@@ -232,7 +233,7 @@ class FlatParams:
     def untouched_ranges(self) -> List[Tuple[int, int]]:
         out = []
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
-            if not self.touched[i]:
+            if not self.touched[i] and i not in self.always_touched:
                 end = o + (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
                 if out and out[-1][1] == o:
                     out[-1] = (out[-1][0], end)
