@@ -71,7 +71,11 @@ def graph_stages(model: nn.Module, x_in: torch.Tensor, stages: Iterable[str] = D
                  autocast_dtype: Optional[torch.dtype] = torch.bfloat16, flat=None) -> List[GraphedStage]:
     """Capture the named stages of `model` (those it has) for inputs shaped like the ones a forward of `x_in` feeds them.
     Call after the parameters have their final storage (train.FlatParams) and after one eager step; pass `flat` so the
-    stages' parameters count as always-touched for the optimizer's "no gradient this step" logic."""
+    stages' parameters count as always-touched for the optimizer's "no gradient this step" logic.  No autograd graph of
+    an earlier step may be alive (drop the last loss tensor first): its AccumulateGrad nodes are bound to the streams of
+    that step, and the engine would tie them into the capture (ROCm 7.2 then crashes in hipStreamEndCapture)."""
+    import gc
+    gc.collect()
     mods = dict(model.named_modules())
     targets: Dict[str, nn.Module] = {}
     installs = {}
