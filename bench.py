@@ -31,6 +31,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+# measured on the pool's MI355X with tools/peaks (profiles/r02_peaks.log): back-to-back v_mfma_f32_32x32x16_bf16 on random
+# data sustain 1 867 TFLOP/s at the 1.84 - 1.87 GHz the chip holds under that load (32.0 cycles per MFMA per SIMD);
+# HBM 16-B-per-lane streams: read 6.45, write 4.55, copy 4.85 TB/s
+PEAK_BF16_TFLOPS_MEASURED = 1867.0
 FLOP_PER_VOLUME = {"ctunet": 10.26e12, "cunet": 5.278e12, "tunet": 3.496e12}  # fwd+bwd, SURVEY.md section 8d
 
 
@@ -91,22 +95,24 @@ class KernelTimer:
 
 
 def pmc_traffic(entry_point):
-    """HBM bytes per launch of the dominant entry point's kernels, from the committed rocprofv3 PMC passes over this very
-    command (profiles/r01_pmc_hbm_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate passes, per the guide's gfx950
-    correction).  Counters cannot be read from inside the process, so this is the last profiled value, not a live one;
-    None when the file is absent or the model is not the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    """(bytes, source): HBM bytes per launch of the dominant entry point's kernels from the newest committed rocprofv3 PMC
+    passes over this very command (profiles/r*_pmc_hbm_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate passes, per
+    the guide's gfx950 correction).  Counters cannot be read from inside the process, so this is the last profiled value
+    (the file name says of which round), not a live one; (None, None) when no file is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    path = files[-1] if files else ""
     key = {"ctu_conv3_halo": "conv3_halo_dma_kernel", "ctu_conv3_halo_wgrad": "conv3_halo_wgrad_dma_kernel",
            "ctu_igemm_nt": "gemm_nt_dma_kernel", "ctu_igemm_tn": "gemm_tn_dma_kernel"}.get(entry_point)
     if key is None or not os.path.exists(path):
-        return None
+        return None, None
     ks = json.load(open(path))["kernels"]
     n = b = 0.0
     for name, v in ks.items():
         if key in name:
             n += v["launches_per_step"]
             b += v["launches_per_step"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
-    return round(b / n) if n else None
+    return (round(b / n) if n else None), os.path.basename(path)
 
 
 def _cpu_model_name():
@@ -297,8 +303,11 @@ def main():
         dom = max(s, key=lambda k: s[k]["flops"])
         tot = {k: round(v["ms"] / 2, 3) for k, v in s.items()}
         ach = s[dom]["flops"] / (s[dom]["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(dom)
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom), "kernel": dom,
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "peak_measured": PEAK_BF16_TFLOPS_MEASURED,
+                    "frac_of_measured_peak": round(ach / PEAK_BF16_TFLOPS_MEASURED, 4), "kernel": dom,
                     "launches_per_step": s[dom]["launches"] // 2,
                     "avg_launch_ms": round(s[dom]["ms"] / s[dom]["launches"], 4),
                     "igemm_ms_per_step": tot,

@@ -20,7 +20,7 @@ def load(d):
 
 F, W = load(sys.argv[1]), load(sys.argv[2])
 steps = float(sys.argv[3])
-out = sys.argv[4] if len(sys.argv) > 4 else "profiles/r01_pmc_hbm_traffic.json"
+out = sys.argv[4] if len(sys.argv) > 4 else "profiles/r02_pmc_hbm_traffic.json"
 rows, tf, tw = [], 0.0, 0.0
 for k in F:
     n = F[k][0]
@@ -33,8 +33,8 @@ rows.sort(reverse=True)
 print(f"per step: fetch {tf / steps / 1e9:.1f} GB, write {tw / steps / 1e9:.1f} GB")
 for t, k, n, fb, wb in rows[:14]:
     print(f"{k:62s} x{n / steps:6.1f}/step  fetch {fb / n / 1e6:8.1f} MB  write {wb / n / 1e6:8.1f} MB per launch  {t / steps / 1e9:6.2f} GB/step")
-json.dump({"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over python bench.py --steps 2 "
-                   "--warmup 1; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md section HBM); bytes per launch "
+json.dump({"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over python bench.py --serial --steps 2 "
+                   "--warmup 1 (single stream: a launch's counters are that kernel's alone); FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md section HBM); bytes per launch "
                    "averaged over the launches of a step",
            "per_step_GB": {"fetch": tf / steps / 1e9, "write": tw / steps / 1e9},
            "kernels": {k: {"launches_per_step": n / steps, "fetch_bytes_per_launch": fb / n, "write_bytes_per_launch": wb / n}
