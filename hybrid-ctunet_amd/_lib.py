@@ -45,7 +45,7 @@ class AttnGeom(C.Structure):
 _SIGS = {
     "ctu_igemm_nt": [_i32, _vp, _vp, _vp, _vp, C.POINTER(Geom), C.POINTER(Epilogue), _vp],
     "ctu_igemm_tn": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, C.POINTER(Geom), _vp, _i64, _vp],
-    "ctu_conv3_halo": [_i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 10 + [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp],
+    "ctu_conv3_halo": [_i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 10 + [_vp, _vp, _vp, _i64, _i32, _vp],
     "ctu_in_finalize": [_i32, _i64, _i32, _vp, _vp, _vp],
     "ctu_conv3_halo_wgrad": [_i32, _vp, _vp, _vp, _vp] + [_i32] * 9 + [_vp],
     "ctu_pack_frag": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp],

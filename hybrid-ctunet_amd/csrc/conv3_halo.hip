@@ -41,14 +41,6 @@ struct HaloArgs {
   // 32-byte pieces of ten different cache lines.
   int vs1;
   int64_t bs1;
-  // Data-gradient launches whose output is the gradient of an InstanceNorm(+LeakyReLU) OUTPUT (the norm sat in front of this
-  // convolution) also produce that norm's two backward sums, so the separate reduction pass over (dy, x) disappears
-  // (ctu_in_bwd_reduce): per batch item and channel  bsums += (sum g, sum g * xhat),  g = dy * act'(xhat),
-  // xhat = (bx - mean) * rstd with (mean, rstd) = bstats[b][c][0..1]; bx is the norm's input, laid out like `out`.
-  const void* bx;
-  const float* bstats;
-  double* bsums;
-  int bact;
   int debug;               // measurement hook (ctu_set_option "nt_debug"): 1 = no output stores, 4 = no weight DMA, 8 = no halo DMA
 };
 
@@ -435,34 +427,21 @@ __global__ __launch_bounds__(256, RD == 2 ? 3 : 2) void conv3_halo_dma_kernel(co
   bf16* out = reinterpret_cast<bf16*>(p.out);
   bf16* out2 = reinterpret_cast<bf16*>(p.out2);
   const int gd = d0 + wave;
-  const bool bwd_sums = p.bsums != nullptr && !p.part;
-  float* bred = reinterpret_cast<float*>(smem + 20 * 1024);  // [4 waves][NT * 32 columns][2] (as the statistics block above)
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int cv = lane & 3;
-    const int n = (nt0 + j) * 32 + cv * 8;
-    float bm[8], br[8], bs1[8], bs2[8];
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { bm[e] = 0.f; br[e] = 0.f; bs1[e] = 0.f; bs2[e] = 0.f; }
-    if (bwd_sums && n < p.N) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        bm[e] = p.bstats[((size_t)b * p.N + n + e) * 2];
-        br[e] = p.bstats[((size_t)b * p.N + n + e) * 2 + 1];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < NT; ++j) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) stage[((e & 3) + 8 * (e >> 2) + 4 * h) * STAGE_LD + r] = acc[i][j][e];
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int vv = lane + 64 * q;  // 128 vectors: 32 rows x 4 groups of 8 channels
-        const int row = vv >> 2;
+        const int row = vv >> 2, cv = vv & 3;
         int hh, ww;
         halo_row_to_hw(row, hh, ww);
         const int gh = h0 + 4 * i + hh, gw = w0 + ww;
+        const int n = (nt0 + j) * 32 + cv * 8;
         if (gd < p.D && gh < p.H && gw < p.W && n < p.N) {
           float xv[8];
           load8(&stage[row * STAGE_LD + cv * 8], xv);
@@ -476,58 +455,12 @@ __global__ __launch_bounds__(256, RD == 2 ? 3 : 2) void conv3_halo_dma_kernel(co
 #pragma unroll
               for (int e = 0; e < 8; ++e) xv[e] += rr[e];
             }
-            if (bwd_sums) {
-              float xr[8];
-              load8(reinterpret_cast<const bf16*>(p.bx) + m * p.ldc + n, xr);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float xh = (xr[e] - bm[e]) * br[e];
-                const float g = (p.bact && !(xh > 0.f)) ? xv[e] * LRELU_SLOPE : xv[e];
-                bs1[e] += g;
-                bs2[e] += g * xh;
-              }
-            }
             if (!(p.debug & 1)) store8(out + m * p.ldc + n, xv);
           }
         }
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if (bwd_sums) {
-      // lanes with equal (lane & 3) hold partial sums of the same 8 channels: fold them, lanes 0 - 3 publish
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-#pragma unroll
-        for (int o = 4; o < 64; o <<= 1) {
-          bs1[e] += __shfl_xor(bs1[e], o, 64);
-          bs2[e] += __shfl_xor(bs2[e], o, 64);
-        }
-      }
-      if (lane < 4) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          bred[(wave * NT * 32 + j * 32 + cv * 8 + e) * 2] = bs1[e];
-          bred[(wave * NT * 32 + j * 32 + cv * 8 + e) * 2 + 1] = bs2[e];
-        }
-      }
-    }
-  }
-  if (bwd_sums) {
-    __syncthreads();
-    if (tid < NT * 32) {
-      const int n = nt0 * 32 + tid;
-      if (n < p.N) {
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int wv = 0; wv < 4; ++wv) {
-          t1 += bred[(wv * NT * 32 + tid) * 2];
-          t2 += bred[(wv * NT * 32 + tid) * 2 + 1];
-        }
-        atomicAdd(&p.bsums[((size_t)b * p.N + n) * 2], (double)t1);
-        atomicAdd(&p.bsums[((size_t)b * p.N + n) * 2 + 1], (double)t2);
-      }
-    }
-  }
 }
 
 // Second pass of a channel-split convolution: out[m][n] = bf16(sum_s part[s][m][n]) and, optionally, the InstanceNorm
@@ -535,9 +468,7 @@ __global__ __launch_bounds__(256, RD == 2 ? 3 : 2) void conv3_halo_dma_kernel(co
 __global__ __launch_bounds__(256) void halo_split_finish_kernel(const float* __restrict__ part, bf16* __restrict__ out,
                                                                 double* __restrict__ in_acc, const int nsplit,
                                                                 const int64_t S, const int64_t rows_total, const int N,
-                                                                const int npad, const int ldc, const int64_t rows_per_block,
-                                                                const bf16* __restrict__ bx, const float* __restrict__ bstats,
-                                                                const int bact) {
+                                                                const int npad, const int ldc, const int64_t rows_per_block) {
   __shared__ float red[256 * 16];
   const int ncg = N >> 3;
   const int tid = threadIdx.x;
@@ -549,18 +480,6 @@ __global__ __launch_bounds__(256) void halo_split_finish_kernel(const float* __r
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-  // bx != NULL: in_acc receives the InstanceNorm BACKWARD sums (sum g, sum g * xhat) of the norm whose output gradient this
-  // is (HaloArgs::bx) instead of the forward statistics (sum y, sum y^2)
-  float bm[8], br[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { bm[e] = 0.f; br[e] = 1.f; }
-  if (bx && rl < rlanes) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      bm[e] = bstats[((size_t)b * N + cg * 8 + e) * 2];
-      br[e] = bstats[((size_t)b * N + cg * 8 + e) * 2 + 1];
-    }
-  }
   if (rl < rlanes) {
     for (int64_t sidx = s_begin + rl; sidx < s_end; sidx += rlanes) {
       const int64_t m = (int64_t)b * S + sidx;
@@ -573,20 +492,8 @@ __global__ __launch_bounds__(256) void halo_split_finish_kernel(const float* __r
         for (int e = 0; e < 8; ++e) v[e] += w[e];
       }
       store8(out + m * ldc + cg * 8, v);
-      if (bx) {
-        float xr[8];
-        load8(bx + m * ldc + cg * 8, xr);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xh = (xr[e] - bm[e]) * br[e];
-          const float g = (bact && !(xh > 0.f)) ? v[e] * LRELU_SLOPE : v[e];
-          s1[e] += g;
-          s2[e] += g * xh;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
-      }
+      for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
     }
   }
   if (!in_acc) return;
@@ -648,8 +555,7 @@ template <> struct HaloDma<bf16> {
       int64_t rpb = (S + chunks - 1) / chunks;
       if (rpb < 16) rpb = 16;
       hipLaunchKernelGGL(halo_split_finish_kernel, dim3((unsigned)((S + rpb - 1) / rpb), p.B), dim3(256), 0, s, ws,
-                         reinterpret_cast<bf16*>(p.out), p.bsums ? p.bsums : p.in_acc, ksplit, S, rows, p.N, ntn * 32, p.ldc, rpb,
-                         reinterpret_cast<const bf16*>(p.bsums ? p.bx : nullptr), p.bstats, p.bact);
+                         reinterpret_cast<bf16*>(p.out), p.in_acc, ksplit, S, rows, p.N, ntn * 32, p.ldc, rpb);
     }
     return true;
   }
@@ -672,8 +578,7 @@ static int launch_halo(const HaloArgs& p, float* ws, int64_t ws_floats, hipStrea
 extern "C" int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, const void* wfrag, void* out, void* out2,
                               int32_t B, int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N,
                               int32_t n_split, int32_t ldc, int32_t ldc2, double* in_acc, const void* residual, float* ws,
-                              int64_t ws_floats, int32_t x1_layout, const void* bwd_x, const float* bwd_stats,
-                              double* bwd_sums, int32_t bwd_act, ctu_stream_t stream) {
+                              int64_t ws_floats, int32_t x1_layout, ctu_stream_t stream) {
   CTU_REQUIRE(x1 && wfrag && out, "conv3_halo: null pointer");
   CTU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3_halo: bad dims");
   CTU_REQUIRE(C1 > 0 && C1 % 32 == 0 && C2 >= 0 && C2 % 32 == 0 && (C2 == 0 || x2), "conv3_halo: C1, C2 must be multiples of 32");
@@ -692,10 +597,6 @@ extern "C" int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, c
   CTU_REQUIRE(x1_layout == CTU_LAYOUT_NDHWC || (x1_layout == CTU_LAYOUT_B16 && dtype == CTU_BF16 &&
                                                (int64_t)B * D * H * W * (C1 > C2 ? C1 : C2) < (1ll << 31)),
               "conv3_halo: the blocked input layout needs the bf16 LDS-DMA kernel");
-  CTU_REQUIRE(!bwd_sums || (bwd_x && bwd_stats && !in_acc && dtype == CTU_BF16 && n_split == 0 && ldc == N &&
-                            (int64_t)B * D * H * W * (C1 > C2 ? C1 : C2) < (1ll << 31)),
-              "conv3_halo: fused InstanceNorm backward sums need the bf16 LDS-DMA kernel, one dense destination, no in_acc");
-  p.bx = bwd_x; p.bstats = bwd_stats; p.bsums = bwd_sums; p.bact = bwd_act;
   p.vs1 = x1_layout == CTU_LAYOUT_B16 ? 16 : C1;
   p.bs1 = x1_layout == CTU_LAYOUT_B16 ? (int64_t)16 * B * D * H * W : 16;
   CTU_REQUIRE(ws_floats >= 0 && (ws_floats == 0 || ws), "conv3_halo: bad workspace");

@@ -517,12 +517,11 @@ class ConvFn(torch.autograd.Function):
     Reference: get_conv_layer, networks/resnet.py:17-50 (3x3x3 s1/s2, 1x1x1 s2)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, stride, padding, grad_stash=None, x1_b16=False, link=None, in_bwd=None):
+    def forward(ctx, x1, x2, weight, stride, padding, grad_stash=None, x1_b16=False, link=None):
         _check_act(x1)
         ctx.grad_stash = grad_stash
         ctx.x1_b16 = bool(x1_b16)
         ctx.link = link
-        ctx.in_bwd = in_bwd if (x2 is None and FUSE_IN_BWD) else None
         B, D, H, W, C1 = x1.shape
         C2 = 0 if x2 is None else x2.shape[-1]
         N = weight.shape[0]
@@ -540,8 +539,7 @@ class ConvFn(torch.autograd.Function):
                 acc = _in_acc_take(x1.device, B * N * 2)
             ws = _tn_workspace(x1.device)
             call("ctu_conv3_halo", dcode(x1.dtype), ptr(x1), ptr(x2), ptr(wfr), ptr(out), None, B, D, H, W, C1, C2, N, 0,
-                 N, 0, ptr(acc[1]) if acc is not None else None, None, ptr(ws), ws.numel(), int(ctx.x1_b16),
-                 None, None, None, 0, stream())
+                 N, 0, ptr(acc[1]) if acc is not None else None, None, ptr(ws), ws.numel(), int(ctx.x1_b16), stream())
             ctx.in_acc = acc
             # the InstanceNorm that follows may hand this conv's data- and weight-gradient kernels their dY in the blocked
             # layout (they are its only readers)
@@ -593,17 +591,8 @@ class ConvFn(torch.autograd.Function):
                     extra = ctx.grad_stash.pop()  # gradient of x1 through another branch: added in the epilogue
                     if extra.shape != x1.shape or extra.dtype != x1.dtype or not extra.is_contiguous():
                         extra = extra.to(x1.dtype).contiguous().view_as(x1)
-                ib = ctx.in_bwd
-                bx = bstats = bsums = None
-                if ib is not None and x2 is None and x1.dtype == torch.bfloat16 and B * D * H * W * max(N, K) < (1 << 31):
-                    # x1 is the output of an InstanceNorm whose backward comes next on this stream: sum its (g, g * xhat) here
-                    inws = _in_workspace(x1.device, B * K * 2)
-                    bsums = inws[1 + inws[3]]      # the clean buffer that backward will pick
-                    bx, bstats = ib.x, ib.stats
-                    ib.filled = (bsums.data_ptr(), inws[3])
                 call("ctu_conv3_halo", dcode(x1.dtype), ptr(gy), None, ptr(wfr), ptr(g1), ptr(g2), B, D, H, W, N, 0, K,
-                     C1 if x2 is not None else 0, C1, C2, None, ptr(extra), ptr(ws), ws.numel(), int(gy_b16),
-                     ptr(bx), ptr(bstats), ptr(bsums), ib.act if bsums is not None else 0, stream())
+                     C1 if x2 is not None else 0, C1, C2, None, ptr(extra), ptr(ws), ws.numel(), int(gy_b16), stream())
             else:
                 # dX[v][c] = sum_t sum_n dY[(v + p - t)/s][n] W[n][c][t]  ->  panel [t][c][n]
                 wd = _packed(weight, "conv_d", x1.dtype,
@@ -638,7 +627,7 @@ class ConvFn(torch.autograd.Function):
                     permute3(panel, gw, (N, K, taps), (K, 1, N * K), (K * taps, taps, 1))
         if ctx.grad_stash:  # not consumed by a fused epilogue (generic path): add it here
             g1 = g1 + ctx.grad_stash.pop().to(g1.dtype)
-        return g1, g2, gw, None, None, None, None, None, None
+        return g1, g2, gw, None, None, None, None, None
 
 
 _PANEL_SCRATCH = {}
@@ -663,21 +652,6 @@ USE_HALO_CONV = True  # tests flip this to run the generic implicit GEMM on the 
 # autograd node and the norm applied to its output share a _B16Link (set in the norm's forward, read in the conv's
 # backward) - the blocked gradient travels along exactly one graph edge.
 B16_LAYOUT = not os.environ.get("CTU_NO_B16")
-
-
-class _InBwdLink:
-    """Shared between an InstanceNorm(+LeakyReLU) and the halo convolution that is the one consumer of its output: the
-    conv's data-gradient launch also accumulates the norm's two backward sums (ctu_conv3_halo bwd_sums), so the norm's
-    backward skips its reduction pass.  `x`, `stats`, `act` describe the norm; `filled` is set by the conv's backward with the
-    workspace buffer it summed into, and consumed by the norm's backward (the next InstanceNorm backward on that stream)."""
-    __slots__ = ("x", "stats", "act", "filled")
-
-    def __init__(self, x, stats, act):
-        self.x, self.stats, self.act, self.filled = x, stats, int(act), None
-
-
-FUSE_IN_BWD = not os.environ.get("CTU_NO_FUSE_IN_BWD")
-_last_in_bwd = None
 
 
 class _B16Link:
@@ -822,8 +796,7 @@ def conv3d(x1, weight, stride=1, padding=0, x2=None, grad_stash=None):
     global _last_b16_grad_ok
     _last_b16_grad_ok = False
     link = _B16Link()
-    out = ConvFn.apply(x1, x2, weight, _t3(stride), _t3(padding), grad_stash, bool(getattr(x1, "_ctu_b16", False)), link,
-                       getattr(x1, "_ctu_in_bwd", None))
+    out = ConvFn.apply(x1, x2, weight, _t3(stride), _t3(padding), grad_stash, bool(getattr(x1, "_ctu_b16", False)), link)
     if _last_in_acc is not None:
         out._ctu_in_acc = _last_in_acc  # instance_norm(out, ...) picks the statistics up instead of re-reading `out`
         _last_in_acc = None
@@ -1024,9 +997,6 @@ class InstanceNormFn(torch.autograd.Function):
             link.gy_b16 = True
             x._ctu_b16_link = None   # one norm per conv output: a second consumer would read a blocked gradient sum
         ctx.has_res = residual is not None
-        ctx.in_bwd = _InBwdLink(x, stats, act) if (out_b16 and FUSE_IN_BWD and ctx.needs_input_grad[0]) else None
-        global _last_in_bwd
-        _last_in_bwd = ctx.in_bwd
         # without a residual sign(y) == sign(xhat): backward recomputes the LeakyReLU mask from x and needs no y
         ctx.save_for_backward(x, y if ctx.has_res else None, stats)
         ctx.act = int(act)
@@ -1047,15 +1017,7 @@ class InstanceNormFn(torch.autograd.Function):
         dc = dcode(x.dtype)
         # (measured: reducing and applying one batch item at a time, hoping the second read hits the 256 MB Infinity
         # Cache, is 2 % slower than one pass over the whole batch)
-        ib = ctx.in_bwd
-        if ib is not None and ib.filled is not None:
-            # the halo convolution behind this norm already summed (g, g * xhat) in its data-gradient epilogue
-            if ib.filled != (sums.data_ptr(), ws[3]):
-                raise RuntimeError("fused InstanceNorm backward sums: another InstanceNorm backward ran on this stream between "
-                                   "the convolution's data gradient and this norm's backward")
-            ib.filled = None
-        else:
-            call("ctu_in_bwd_reduce", dc, ptr(gy), ptr(x), ptr(y), ptr(stats), ptr(sums), B, S, C, ctx.act, stream())
+        call("ctu_in_bwd_reduce", dc, ptr(gy), ptr(x), ptr(y), ptr(stats), ptr(sums), B, S, C, ctx.act, stream())
         call("ctu_in_bwd_apply", dc, ptr(gy), ptr(x), ptr(y), ptr(stats), ptr(sums), ptr(gx), ptr(gres), B, S, C,
              ctx.act, ptr(dirty), dirty_n, int(ctx.dx_b16), stream())
         ws[3] ^= 1
@@ -1080,13 +1042,9 @@ def _in_workspace(device, n):
 
 def instance_norm(x, residual=None, act=False, out_b16: bool = False):
     """out_b16: write the result in CTU_LAYOUT_B16 - only when its one consumer is a 3x3x3 halo convolution (wants_b16)."""
-    global _last_in_bwd
-    _last_in_bwd = None
     y = InstanceNormFn.apply(x, residual, act, out_b16)
     if out_b16:
         y._ctu_b16 = True   # ops.conv3d reads the mark; nothing else may consume y
-        y._ctu_in_bwd = _last_in_bwd
-    _last_in_bwd = None
     return y
 
 

@@ -151,17 +151,11 @@ int ctu_conv_cin1_wgrad(ctu_dtype dtype, const void* x, const void* dy, float* d
  * ws (optional fp32 scratch, ws_floats entries, contents irrelevant): volumes of a few bricks (the 12x12x24 and
  * 6x6x12 stages) split their input channels over workgroups, keep fp32 partial outputs there and sum them in a
  * second pass (bf16, n_split == 0).
- * x1_layout: ctu_layout of x1 (x2 is always channels-last).
- * bwd_sums (optional, fp64 [B][N][2], zero on entry; bf16, n_split == 0, ldc == N, no in_acc): for a DATA-GRADIENT launch whose
- * output is the gradient of an InstanceNorm(+LeakyReLU) output - the norm in front of this convolution in the forward
- * pass (resnet.py:106-113, hybrid_CTUNet.py:93-99) - the epilogue also accumulates that norm's two backward sums
- * (sum g, sum g*xhat), g = dy*act'(xhat), xhat = (bwd_x - mean)*rstd, (mean, rstd) = bwd_stats[b][c]; bwd_x = the norm's
- * input [rows][N].  ctu_in_bwd_reduce is then not needed for that norm: ctu_in_bwd_apply takes bwd_sums directly. */
+ * x1_layout: ctu_layout of x1 (x2 is always channels-last). */
 int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, const void* wfrag, void* out, void* out2,
                    int32_t B, int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N, int32_t n_split,
                    int32_t ldc, int32_t ldc2, double* in_acc, const void* residual, float* ws, int64_t ws_floats,
-                   int32_t x1_layout, const void* bwd_x, const float* bwd_stats, double* bwd_sums, int32_t bwd_act,
-                   ctu_stream_t stream);
+                   int32_t x1_layout, ctu_stream_t stream);
 /* Weight gradient of the same convolution with the halo staged once per brick:
  * dw[27][N][C1+C2] += sum_v dy[v][n] * x[v + tap - 1][c]  (fp32 atomics into a zeroed panel). dy: [B][D][H][W][N]. */
 int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void* x1, const void* x2, float* dw, int32_t B,
