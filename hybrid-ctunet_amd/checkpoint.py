@@ -47,17 +47,24 @@ def load_checkpoint(model, checkpoint, strict: bool = False, optimizer=None) -> 
     epoch = int(checkpoint.get("epoch", 0)) if isinstance(checkpoint, dict) else 0
     best = float(checkpoint.get("best_acc", 0)) if isinstance(checkpoint, dict) else 0.0
     if optimizer is not None and isinstance(checkpoint, dict) and "optimizer" in checkpoint:
-        optimizer.load_state_dict(checkpoint["optimizer"])
+        osd = checkpoint["optimizer"]
+        if hasattr(optimizer, "flat") and "state" in osd:
+            # torch.optim.AdamW's format (what the reference saves) into the fused optimizer: positions follow model.parameters()
+            optimizer.load_state_dict(osd, params=list(net.parameters()))
+        else:
+            optimizer.load_state_dict(osd)
     return epoch, best
 
 
 def save_checkpoint(model, epoch: int, filename: str, best_acc: float = 0, optimizer=None, scheduler=None) -> str:
     """Write the file the reference's tools read back (trainer_CTUNet.py:308-317): the unwrapped network's state_dict
-    (fp32 tensors in the reference's key order), epoch, best_acc and, optionally, optimizer / scheduler state."""
+    (fp32 tensors in the reference's key order), epoch, best_acc and, optionally, optimizer / scheduler state.  The fused
+    optimizer's state is written in torch.optim.AdamW's format, so torch.optim.AdamW (the reference) can resume from it."""
     sd = OrderedDict((k, v.detach().cpu()) for k, v in unwrap(model).state_dict().items())
     save = {"epoch": epoch, "best_acc": best_acc, "state_dict": sd}
     if optimizer is not None:
-        save["optimizer"] = optimizer.state_dict()
+        save["optimizer"] = optimizer.state_dict(params=list(unwrap(model).parameters())) if hasattr(optimizer, "flat") \
+            else optimizer.state_dict()
     if scheduler is not None:
         save["scheduler"] = scheduler.state_dict()
     torch.save(save, filename)

@@ -23,6 +23,10 @@ LRELU_SLOPE = 0.01
 # side streams (CTUNet runs its two independent encoder branches on two HIP streams; autograd replays each node on the
 # stream its forward ran on).  Whoever consumes results on the main stream joins them first.
 # ---------------------------------------------------------------------------------------------------------------
+if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    # (parameters of the two branches are touched from different streams step after step: expected here)
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
 _side_streams = {}
 _used_side = set()   # keys of side streams handed out since the last join_side_streams()
 _ws_epoch = 0        # bumped by new_workspace_epoch(): a HIP-graph capture gets per-stream workspaces of its own

@@ -298,24 +298,80 @@ class FusedAdamW:
     def zero_grad(self, set_to_none: bool = False):
         self.flat.zero_grad()
 
-    def state_dict(self):
-        """Flat optimizer state (for checkpoint.save_checkpoint): step count, hyper-parameters and the two moment buffers
-        in FlatParams order together with the parameter shapes that define that order."""
-        return {"step": self.device_step_count(), "param_groups": [dict(g) for g in self.param_groups],
-                "shapes": [tuple(p.shape) for p in self.flat.params], "offsets": list(self.flat.offsets),
-                "exp_avg": self.m.detach().cpu(), "exp_avg_sq": self.v.detach().cpu()}
+    def state_dict(self, params: Optional[Iterable[nn.Parameter]] = None):
+        """Optimizer state.  With `params` (the parameters in the order a torch.optim.AdamW would have received them,
+        e.g. model.parameters()): torch.optim.AdamW's own format - `state` {index: step, exp_avg, exp_avg_sq} +
+        `param_groups` - which the reference's tools and torch.optim.AdamW.load_state_dict read
+        (trainer_CTUNet.py:311-312 saves exactly that).  Without: the flat form (step count, hyper-parameters, the two
+        moment buffers in FlatParams order with the shapes that define the order)."""
+        step = self.device_step_count()
+        if params is None:
+            return {"step": step, "param_groups": [dict(g) for g in self.param_groups],
+                    "shapes": [tuple(p.shape) for p in self.flat.params], "offsets": list(self.flat.offsets),
+                    "exp_avg": self.m.detach().cpu(), "exp_avg_sq": self.v.detach().cpu()}
+        where = {id(p): (o, p.numel()) for p, o in zip(self.flat.params, self.flat.offsets)}
+        skipped = self._static_skip if self._static_skip is not None else []
+        state, idx = {}, []
+        for i, p in enumerate(params):
+            idx.append(i)
+            if id(p) not in where:
+                continue
+            o, n = where[id(p)]
+            if step == 0 or any(a <= o < b for a, b in skipped):
+                continue   # torch keeps no state for a parameter that never saw a gradient
+            state[i] = {"step": torch.tensor(float(step)), "exp_avg": self.m[o:o + n].view(p.shape).detach().cpu().clone(),
+                        "exp_avg_sq": self.v[o:o + n].view(p.shape).detach().cpu().clone()}
+        g0 = self.param_groups[0]
+        group = {"lr": g0["lr"], "betas": tuple(g0["betas"]), "eps": g0["eps"], "weight_decay": g0["weight_decay"],
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "decoupled_weight_decay": True, "params": idx}
+        return {"state": state, "param_groups": [group]}
 
-    def load_state_dict(self, sd):
-        if [tuple(s) for s in sd["shapes"]] != [tuple(p.shape) for p in self.flat.params]:
-            raise ValueError("optimizer state was saved for a different parameter order / model")
-        self.step_count = int(sd["step"])
+    def load_state_dict(self, sd, params: Optional[Iterable[nn.Parameter]] = None):
+        """Accepts the flat form and torch.optim.AdamW's form (a checkpoint written by the reference,
+        trainer_CTUNet.py:311-312); the latter needs `params` = the parameters in the order that optimizer was built
+        with (model.parameters() in main_CTUNet.py:192)."""
+        if "state" in sd:
+            if params is None:
+                raise ValueError("a torch.optim.AdamW state dict is indexed by parameter position: pass params=model.parameters()")
+            where = {id(p): (o, p.numel()) for p, o in zip(self.flat.params, self.flat.offsets)}
+            plist = list(params)
+            index_of = {}
+            for g in sd["param_groups"]:
+                for pos in g["params"]:
+                    index_of[pos] = plist[pos] if pos < len(plist) else None
+            self.m.zero_()
+            self.v.zero_()
+            steps = []
+            for pos, st in sd["state"].items():
+                p = index_of.get(int(pos))
+                if p is None or id(p) not in where:
+                    raise ValueError(f"optimizer state entry {pos} has no matching parameter")
+                o, n = where[id(p)]
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state entry {pos}: shape {tuple(st['exp_avg'].shape)} != {tuple(p.shape)}")
+                self.m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                self.v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.append(int(float(st["step"])))
+            if steps and min(steps) != max(steps):
+                raise ValueError("per-parameter step counts differ: the fused optimizer keeps one")
+            self.step_count = steps[0] if steps else 0
+            g0 = sd["param_groups"][0]
+            self.param_groups = [{"lr": g0["lr"], "betas": tuple(g0["betas"]), "eps": g0["eps"],
+                                  "weight_decay": g0["weight_decay"]}]
+        else:
+            if [tuple(s) for s in sd["shapes"]] != [tuple(p.shape) for p in self.flat.params]:
+                raise ValueError("optimizer state was saved for a different parameter order / model")
+            self.step_count = int(sd["step"])
+            self.param_groups = [dict(g) for g in sd["param_groups"]]
+            self.m.copy_(sd["exp_avg"])
+            self.v.copy_(sd["exp_avg_sq"])
         if self.hyper is not None:
             self.hyper[1:2].view(torch.int32).fill_(self.step_count)
-        self.param_groups = [dict(g) for g in sd["param_groups"]]
         g0 = self.param_groups[0]
         self.lr, self.betas, self.eps, self.weight_decay = g0["lr"], tuple(g0["betas"]), g0["eps"], g0["weight_decay"]
-        self.m.copy_(sd["exp_avg"])
-        self.v.copy_(sd["exp_avg_sq"])
+        if self.hyper is not None:
+            self.hyper[0:1].fill_(float(self.lr))
 
     def freeze_skip_ranges(self):
         """After one real backward: remember which parameters never receive a gradient, so later steps (e.g. replayed

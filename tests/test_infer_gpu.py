@@ -220,3 +220,45 @@ def test_optimizer_state_round_trip(tmp_path):
         assert torch.allclose(p, q, rtol=0, atol=5e-3) and (p - q).abs().mean() < 1e-4
     with pytest.raises(ValueError):
         H.FusedAdamW(H.build_model("cunet", model_depth=101).to(DEV).parameters()).load_state_dict(opt.state_dict())
+
+
+def test_optimizer_state_interop_with_torch_adamw(tmp_path):
+    """ADVICE r1 (low): a checkpoint the reference wrote holds torch.optim.AdamW's state dict (trainer_CTUNet.py:311-312);
+    FusedAdamW must resume from it, and torch.optim.AdamW must resume from what save_checkpoint writes for FusedAdamW."""
+    torch.manual_seed(3)
+    net = H.build_model("cunet", model_depth=50).to(DEV).set_precision("bf16")
+    x = torch.rand(1, 1, 96, 96, 96, device=DEV)
+    y = torch.randint(0, 14, (1, 1, 96, 96, 96), device=DEV).float()
+    ref_opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-5)
+    for _ in range(2):
+        for p in net.parameters():
+            p.grad = None
+        H.cunet_loss(net(x), y).backward()
+        ref_opt.step()
+    ck = {"epoch": 2, "best_acc": 0.5, "state_dict": {k: v.detach().cpu() for k, v in net.state_dict().items()},
+          "optimizer": ref_opt.state_dict()}                      # what trainer_CTUNet.py:308-317 writes
+    torch.save(ck, str(tmp_path / "ref.pt"))
+    net2 = H.build_model("cunet", model_depth=50).to(DEV).set_precision("bf16")
+    fused = H.FusedAdamW(net2.parameters(), lr=1.0, weight_decay=0.5)
+    assert H.load_checkpoint(net2, str(tmp_path / "ref.pt"), strict=True, optimizer=fused) == (2, 0.5)
+    assert fused.step_count == 2 and fused.lr == pytest.approx(1e-3) and fused.weight_decay == pytest.approx(1e-5)
+    where = {id(p): (o, p.numel()) for p, o in zip(fused.flat.params, fused.flat.offsets)}
+    for (k, p2), p1 in zip(net2.named_parameters(), net.parameters()):
+        st = ref_opt.state.get(p1)
+        o, n = where[id(p2)]
+        if st:
+            assert torch.equal(fused.m[o:o + n].view(p2.shape), st["exp_avg"]), k
+            assert torch.equal(fused.v[o:o + n].view(p2.shape), st["exp_avg_sq"]), k
+        else:
+            assert float(fused.m[o:o + n].abs().max()) == 0.0, k
+    # and back: torch.optim.AdamW reads the file save_checkpoint writes for the fused optimizer
+    f = H.save_checkpoint(net2, 3, str(tmp_path / "fused.pt"), optimizer=fused)
+    back = torch.load(f, map_location="cpu", weights_only=True)
+    opt3 = torch.optim.AdamW(net.parameters(), lr=0.3)
+    opt3.load_state_dict(back["optimizer"])
+    assert opt3.param_groups[0]["lr"] == pytest.approx(1e-3)
+    for p1 in net.parameters():
+        st = ref_opt.state.get(p1)
+        if st:
+            assert torch.equal(opt3.state[p1]["exp_avg"].cpu(), st["exp_avg"].cpu())
+            assert float(opt3.state[p1]["step"]) == 2.0
