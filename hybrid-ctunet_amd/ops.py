@@ -40,11 +40,18 @@ def new_workspace_epoch():
     _ws_epoch += 1
 
 
+# HIP stream priorities (range on this device: 0 = normal, -1 = high).  Measured with every combination for the branch /
+# weight-gradient streams: 49.1 - 49.8 ms per step, no trend - all streams stay at the default.
+WGRAD_PRIORITY = int(os.environ.get("CTU_WGRAD_PRIORITY", "0"))
+BRANCH_PRIORITY = int(os.environ.get("CTU_BRANCH_PRIORITY", "0"))
+
+
 def side_stream(device, tag="branch"):
     key = (device, tag)
     st = _side_streams.get(key)
     if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=device)
+        prio = WGRAD_PRIORITY if isinstance(tag, tuple) and tag[0] == "wgrad" else BRANCH_PRIORITY
+        st = _side_streams[key] = torch.cuda.Stream(device=device, priority=prio)
     _used_side.add(key)
     return st
 
