@@ -227,11 +227,15 @@ __device__ __forceinline__ void halo_row_to_hw(int row, int& hh, int& ww) {
 
 // RD = depth of the weight ring: RD - 1 stages are in flight ahead of the one computed.  NT <= 2 takes RD = 2: with
 // 51 KiB of LDS and ~110 VGPRs three workgroups fit a CU, and their interleaving hides more than a deeper ring does.
-template <int NT, int RD = (NT <= 2 ? 2 : 3)>
-__global__ __launch_bounds__(256, RD == 2 ? 3 : 2) void conv3_halo_dma_kernel(const HaloArgs p) {
+// TPS = taps per weight stage: 3 (one (td, th) row of taps; nine stages and barriers per half chunk) or 9 (one td plane; three
+// stages per half chunk: a two-deep ring then prefetches 9 taps = 1 152 MFMA cycles ahead at NT = 2 instead of 384, for 75 KiB of
+// LDS and two workgroups per CU instead of three - ctu_set_option("route", 16), measured in DESIGN.md section 8).
+template <int NT, int RD = (NT <= 2 ? 2 : 3), int TPS = 3>
+__global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo_dma_kernel(const HaloArgs p) {
   constexpr int HINS = 19;            // DMA wave-instructions per halo half chunk (1216 slots >= 600 voxels x 2)
   constexpr int HBUF = HINS * 1024;
-  constexpr int SFR = 3 * NT;         // weight fragments (1 KiB each) per stage of 3 taps
+  constexpr int SPC = 27 / TPS;       // stages per half chunk
+  constexpr int SFR = TPS * NT;       // weight fragments (1 KiB each) per stage
   constexpr int SBYTES = SFR * 1024;
   constexpr int RING0 = 2 * HBUF;
   constexpr int STAGE_LD = 32 + 4;
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256, RD == 2 ? 3 : 2) void conv3_halo_dma_kernel(co
   const int nt0 = blockIdx.y * NT;
   const int hc_b = blockIdx.z * p.hc_per_split;                      // this workgroup's range of 16-channel half chunks
   const int HC = min((p.C1 + p.C2) / 16, hc_b + p.hc_per_split);    // (exclusive end)
-  const int U = (HC - hc_b) * 9;                                     // stages
+  const int U = (HC - hc_b) * SPC;                                   // stages
   const bf16* x1 = reinterpret_cast<const bf16*>(p.x1);
   const bf16* x2 = reinterpret_cast<const bf16*>(p.x2);
   const bf16* wf = reinterpret_cast<const bf16*>(p.wfrag);
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(256, RD == 2 ? 3 : 2) void conv3_halo_dma_kernel(co
     }
     hm[k] = m;
   }
-  constexpr int BW = SFR / 3;  // weight DMA instructions per loader wave (1 - 3) and stage: NT
+  constexpr int BW = SFR / 3;  // weight DMA instructions per loader wave (1 - 3) and stage: NT (3-tap stages), 3 NT (9-tap)
 
   auto issue_halo = [&](int hc) {  // wave 0 only
     if (p.debug & 8) return;
@@ -310,8 +314,20 @@ __global__ __launch_bounds__(256, RD == 2 ? 3 : 2) void conv3_halo_dma_kernel(co
   }
   auto issue_b = [&](int hc, int s, int slot) {  // waves 1 - 3 only
     if (p.debug & 4) return;
-    const bf16* base = wf + ((size_t)(((hc >> 1) * 27 + 3 * s) * 2 + (hc & 1)) * p.ntn + nt0) * 512;
-    dma16_groupN<BW, 3072>(base, bvoff, smem + RING0 + slot * SBYTES + (wave - 1) * 1024);
+    const bf16* base = wf + ((size_t)(((hc >> 1) * 27 + TPS * s) * 2 + (hc & 1)) * p.ntn + nt0) * 512;
+    unsigned char* dst = smem + RING0 + slot * SBYTES + (wave - 1) * 1024;
+    if constexpr (BW == 1 || BW == 2 || BW == 4) {
+      dma16_groupN<BW, 3072>(base, bvoff, dst);
+    } else if constexpr (BW == 3) {
+      const unsigned a[2] = {bvoff[0], bvoff[1]}, c[1] = {bvoff[2]};
+      dma16_groupN<2, 3072>(base, a, dst);
+      dma16_groupN<1, 3072>(base, c, dst + 2 * 3072);
+    } else {
+      static_assert(BW == 6, "weight instructions per loader wave");
+      const unsigned a[4] = {bvoff[0], bvoff[1], bvoff[2], bvoff[3]}, c[2] = {bvoff[4], bvoff[5]};
+      dma16_groupN<4, 3072>(base, a, dst);
+      dma16_groupN<2, 3072>(base, c, dst + 4 * 3072);
+    }
   };
 
   f32x16 acc[2][NT];
@@ -345,34 +361,38 @@ __global__ __launch_bounds__(256, RD == 2 ? 3 : 2) void conv3_halo_dma_kernel(co
       issue_b(ihc, is, irs);  // past the end: refetches the last stage into a slot nobody reads (keeps the counts)
     }
     if (u + RD < U) {
-      if (++is == 9) { is = 0; ++ihc; }
+      if (++is == SPC) { is = 0; ++ihc; }
     }
     irs = irs == RD - 1 ? 0 : irs + 1;
 
-    const int td = (s * 11) >> 5, th = s - 3 * td;
+    const int td = TPS == 9 ? s : ((s * 11) >> 5);
     const unsigned char* hb = smem + (hc & 1) * HBUF;
     const unsigned char* rb = smem + RING0 + rs * SBYTES + lane * 16;
-    int aoff[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int R = (wave + td) * HALO_H + 4 * i + vrow + th;
-      aoff[i] = ((R * HALO_W + vcol) * 2 + (h ^ ((R >> 1) & 1))) * 16;
+    for (int t3 = 0; t3 < TPS / 3; ++t3) {
+      const int th = TPS == 9 ? t3 : s - 3 * td;
+      int aoff[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int R = (wave + td) * HALO_H + 4 * i + vrow + th;
+        aoff[i] = ((R * HALO_W + vcol) * 2 + (h ^ ((R >> 1) & 1))) * 16;
+      }
+      // (measured: requesting the fragments of all three taps up front + s_setprio around the 6 NT MFMAs is 5-10 % SLOWER
+      // than letting hipcc interleave reads and MFMAs tap by tap - the second wave of the SIMD hides the read latency)
+#pragma unroll
+      for (int tw = 0; tw < 3; ++tw) {
+        bf16x8 fa[2], fb[NT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(hb + aoff[i] + tw * 32);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(rb + ((t3 * 3 + tw) * NT + j) * 1024);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
     }
-    // (measured: requesting the fragments of all three taps up front + s_setprio around the 6 NT MFMAs is 5-10 % SLOWER
-    // than letting hipcc interleave reads and MFMAs tap by tap - the second wave of the SIMD hides the read latency)
-#pragma unroll
-    for (int tw = 0; tw < 3; ++tw) {
-      bf16x8 fa[2], fb[NT];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(hb + aoff[i] + tw * 32);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(rb + (tw * NT + j) * 1024);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-    if (++s == 9) { s = 0; ++hc; }
+    if (++s == SPC) { s = 0; ++hc; }
     rs = rs == RD - 1 ? 0 : rs + 1;
   }
   wait_vm_then_barrier<0>();  // the tail refetches have landed; LDS is free for the epilogue
@@ -545,8 +565,11 @@ template <> struct HaloDma<bf16> {
     ksplit = (HCT + q.hc_per_split - 1) / q.hc_per_split;
     q.part = ksplit > 1 ? ws : nullptr;
     const dim3 grid(bricks, ntn / NT, ksplit);
+    const bool long_stages = (ctu_option_route() & CTU_ROUTE_HALO_TPS9) != 0;
     if (NT == 4) hipLaunchKernelGGL(conv3_halo_dma_kernel<4>, grid, dim3(256), 0, s, q);
+    else if (NT == 2 && long_stages) hipLaunchKernelGGL((conv3_halo_dma_kernel<2, 2, 9>), grid, dim3(256), 0, s, q);
     else if (NT == 2) hipLaunchKernelGGL(conv3_halo_dma_kernel<2>, grid, dim3(256), 0, s, q);
+    else if (long_stages) hipLaunchKernelGGL((conv3_halo_dma_kernel<1, 2, 9>), grid, dim3(256), 0, s, q);
     else hipLaunchKernelGGL(conv3_halo_dma_kernel<1>, grid, dim3(256), 0, s, q);
     if (ksplit > 1) {
       const int64_t S = (int64_t)p.D * p.H * p.W;

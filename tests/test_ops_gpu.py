@@ -626,3 +626,29 @@ def test_b16_layout_chain_equals_channels_last(ops, case):
         else:
             assert (a - b).abs().max().item() <= 1e-2 * scale, name
             assert (a == b).float().mean().item() > 0.99, name
+
+
+@pytest.mark.parametrize("case", [(2, 8, 16, 16, 64, 64), (1, 5, 9, 11, 32, 32), (2, 4, 8, 8, 96, 64)])
+def test_conv3d_halo_long_weight_stages_bit_equal(ops, case):
+    """ctu_set_option("route", 16): the halo kernels with one or two n tiles fetch their weights in 9-tap stages (three per half
+    chunk) instead of 3-tap stages.  Same products in the same order into the same accumulators: forward output and data
+    gradient must be bit-equal to the default kernel's."""
+    from hybrid_ctunet_amd import _lib
+    B, D, H, W, C, N = case
+    x0 = rnd((B, D, H, W, C), 21).to(torch.bfloat16).cuda()
+    w = torch.nn.Parameter(rnd((N, C, 3, 3, 3), 22, 1 / math.sqrt(27 * C)).float().cuda())
+    gout = rnd((B, D, H, W, N), 23).to(torch.bfloat16).cuda()
+
+    def run(route):
+        _lib.call("ctu_set_option", b"route", route)
+        try:
+            x = x0.clone().requires_grad_(True)
+            w.grad = None
+            y = ops.conv3d(x, w, 1, 1)
+            y.backward(gout)
+            torch.cuda.synchronize()
+            return y.detach().clone(), x.grad.clone()
+        finally:
+            _lib.call("ctu_set_option", b"route", 0)
+    a, b = run(0), run(16)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

@@ -176,6 +176,9 @@ CASES = {
                            halo(2, 24, 24, 48, 256, 256, "wgrad"), halo(2, 48, 48, 96, 32, 32, "wgrad")],
 }
 
+if os.environ.get("KB_ROUTE"):
+    call("ctu_set_option", b"route", int(os.environ["KB_ROUTE"]))
+
 if __name__ == "__main__":
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     for k, fn in CASES.items():
