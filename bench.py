@@ -241,7 +241,8 @@ def main():
     if a.stage_graphs and not a.serial and use_bf16:
         # the launch-latency-bound stages (ResNet layer3 / layer4, ViT trunk, first window stages) as HIP graphs
         loss = None   # (no autograd graph of an earlier step may be alive during a capture: its AccumulateGrad nodes carry streams)
-        stages = H.graph_stages(model, x, flat=flat)
+        names = os.environ.get("CTU_STAGES")
+        stages = H.graph_stages(model, x, flat=flat, **({"stages": names.split(",")} if names else {}))
         graph_note = f"eager, {len(stages)} small stages replayed from HIP graphs"
         for _ in range(2):
             loss = step()
