@@ -42,6 +42,7 @@ struct HaloArgs {
   int vs1;
   int64_t bs1;
   int debug;               // measurement hook (ctu_set_option "nt_debug"): 1 = no output stores, 4 = no weight DMA, 8 = no halo DMA
+  void* part_stamps;       // nt_debug & 16: the workspace receives the STAMP build's cycle sums instead of split partials
 };
 
 template <typename T, int NT>
@@ -230,8 +231,14 @@ __device__ __forceinline__ void halo_row_to_hw(int row, int& hh, int& ww) {
 // TPS = taps per weight stage: 3 (one (td, th) row of taps; nine stages and barriers per half chunk) or 9 (one td plane; three
 // stages per half chunk: a two-deep ring then prefetches 9 taps = 1 152 MFMA cycles ahead at NT = 2 instead of 384, for 75 KiB of
 // LDS and two workgroups per CU instead of three - ctu_set_option("route", 16), measured in DESIGN.md section 8).
-template <int NT, int RD = (NT <= 2 ? 2 : 3), int TPS = 3>
+// STAMP (diagnostic build, ctu_set_option("nt_debug", 16); never launched by the product): every wave accumulates the shader
+// cycles it spends (0) before its first stage barrier opens, (1) waiting at stage barriers (own DMA wait + s_barrier),
+// (2) between barriers (fragment reads + MFMAs + DMA issue), (3) in the epilogue, and writes the four sums to
+// stamps[workgroup][wave][4] - memory nothing else reads (MI355X_MICROARCH.md, in-kernel stamps).
+template <int NT, int RD = (NT <= 2 ? 2 : 3), int TPS = 3, bool STAMP = false>
 __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo_dma_kernel(const HaloArgs p) {
+  unsigned long long st_t0 = 0, st_wait = 0, st_work = 0, st_pro = 0, st_mark = 0;
+  if (STAMP) st_t0 = st_mark = __builtin_amdgcn_s_memtime();
   constexpr int HINS = 19;            // DMA wave-instructions per halo half chunk (1216 slots >= 600 voxels x 2)
   constexpr int HBUF = HINS * 1024;
   constexpr int SPC = 27 / TPS;       // stages per half chunk
@@ -287,7 +294,8 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
   }
   constexpr int BW = SFR / 3;  // weight DMA instructions per loader wave (1 - 3) and stage: NT (3-tap stages), 3 NT (9-tap)
 
-  auto issue_halo = [&](int hc) {  // wave 0 only
+  // gather pieces [k0, k1) of half chunk hc (wave 0 only; k0, k1 wave-uniform, hm[] keeps static indices)
+  auto issue_halo = [&](int hc, int k0, int k1) {
     if (p.debug & 8) return;
     const int c0 = hc * 16;
     const bool first = c0 < p.C1;
@@ -298,9 +306,11 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
     unsigned char* dst = smem + (hc & 1) * HBUF;
 #pragma unroll
     for (int k = 0; k < HINS; ++k) {
-      const bf16* g = hm[k] >= 0 ? src + (size_t)hm[k] * vs + ((hpart >> k) & 1) * 8
-                                 : reinterpret_cast<const bf16*>(g_zero16);
-      dma16(g, dst + k * 1024);
+      if (k >= k0 && k < k1) {
+        const bf16* g = hm[k] >= 0 ? src + (size_t)hm[k] * vs + ((hpart >> k) & 1) * 8
+                                   : reinterpret_cast<const bf16*>(g_zero16);
+        dma16(g, dst + k * 1024);
+      }
     }
   };
   // weight stage = fragments f = wave, wave + 4, wave + 8 of this wave: per-lane byte offsets inside the stage are
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
   halo_row_to_hw(r, vrow, vcol);
 
   if (wave == 0) {
-    issue_halo(hc_b);
+    issue_halo(hc_b, 0, HINS);
   } else {
     issue_b(hc_b, 0, 0);
     if (RD == 3) issue_b(hc_b, 1, 1);
@@ -350,15 +360,28 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
   int hc = hc_b, s = 0, rs = 0;               // stage being computed: half chunk, (td, th) index, ring slot
   int ihc = hc_b, is = RD - 1, irs = RD - 1;  // stage being fetched (RD - 1 ahead)
   for (int u = 0; u < U; ++u) {
+    if (STAMP) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (u > 0) st_work += t - st_mark;
+      st_mark = t;
+    }
     if (wave == 0) {
       // the halo of this chunk (issued nine stages ago, the only vector-memory traffic of this wave) has landed
       if (s == 0) wait_vm_then_barrier<0>();
       else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (s == 0 && hc + 1 < HC) issue_halo(hc + 1);  // into the buffer whose last readers passed this barrier
+      // the next half chunk's 19 gather pieces go out in ONE burst, into the buffer whose last readers passed this barrier
+      // (dealt out three per stage, or one per tap behind the MFMAs, this wave reaches more barriers late and every wave
+      // waits longer: +3.5 % / +10 % kernel time)
+      if (s == 0 && hc + 1 < HC) issue_halo(hc + 1, 0, HINS);
     } else {
       // own weight DMAs of this stage have landed; still in flight: the RD - 2 younger stages
       wait_vm_then_barrier<(RD - 2) * BW>();
       issue_b(ihc, is, irs);  // past the end: refetches the last stage into a slot nobody reads (keeps the counts)
+    }
+    if (STAMP) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (u == 0) st_pro = t - st_t0; else st_wait += t - st_mark;
+      st_mark = t;
     }
     if (u + RD < U) {
       if (++is == SPC) { is = 0; ++ihc; }
@@ -396,6 +419,11 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
     rs = rs == RD - 1 ? 0 : rs + 1;
   }
   wait_vm_then_barrier<0>();  // the tail refetches have landed; LDS is free for the epilogue
+  if (STAMP) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    st_work += t - st_mark;
+    st_mark = t;
+  }
 
   if (p.in_acc && !p.part) {
     // InstanceNorm statistics of this output, taken from the fp32 accumulators: the separate pass that re-reads the
@@ -481,6 +509,11 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
       }
       __builtin_amdgcn_wave_barrier();
     }
+  if (STAMP && lane == 0) {
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.part_stamps) +
+                              ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4 + wave) * 4;
+    dst[0] = st_pro; dst[1] = st_wait; dst[2] = st_work; dst[3] = __builtin_amdgcn_s_memtime() - st_mark;
+  }
 }
 
 // Second pass of a channel-split convolution: out[m][n] = bf16(sum_s part[s][m][n]) and, optionally, the InstanceNorm
@@ -564,7 +597,14 @@ template <> struct HaloDma<bf16> {
     q.hc_per_split = (HCT + ksplit - 1) / ksplit;
     ksplit = (HCT + q.hc_per_split - 1) / q.hc_per_split;
     q.part = ksplit > 1 ? ws : nullptr;
+    q.part_stamps = nullptr;
     const dim3 grid(bricks, ntn / NT, ksplit);
+    if ((q.debug & 16) && ksplit == 1 && ws && ws_floats >= (int64_t)grid.x * grid.y * 32 && NT >= 2) {   // diagnostic build
+      q.part_stamps = ws;
+      if (NT == 4) hipLaunchKernelGGL((conv3_halo_dma_kernel<4, 3, 3, true>), grid, dim3(256), 0, s, q);
+      else hipLaunchKernelGGL((conv3_halo_dma_kernel<2, 2, 3, true>), grid, dim3(256), 0, s, q);
+      return true;
+    }
     const bool long_stages = (ctu_option_route() & CTU_ROUTE_HALO_TPS9) != 0;
     if (NT == 4) hipLaunchKernelGGL(conv3_halo_dma_kernel<4>, grid, dim3(256), 0, s, q);
     else if (NT == 2 && long_stages) hipLaunchKernelGGL((conv3_halo_dma_kernel<2, 2, 9>), grid, dim3(256), 0, s, q);
