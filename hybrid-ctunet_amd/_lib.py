@@ -57,9 +57,9 @@ _SIGS = {
     "ctu_colsum": [_i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
     "ctu_outer_rows": [_i32, _vp, _vp, _vp, _i64, _i32, _vp],
     "ctu_in_stats": [_i32, _vp, _i32, _i64, _i32, _vp, _vp, _vp],
-    "ctu_in_apply": [_i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp],
-    "ctu_in_bwd_reduce": [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp],
-    "ctu_in_bwd_apply": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i32, _i32, _vp],
+    "ctu_in_apply": [_i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp],
+    "ctu_in_bwd_reduce": [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp],
+    "ctu_in_bwd_apply": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _vp],
     "ctu_layernorm_fwd": [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "ctu_layernorm_bwd": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "ctu_layernorm_bwd_add": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],

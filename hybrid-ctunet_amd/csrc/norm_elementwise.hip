@@ -95,7 +95,8 @@ __device__ __forceinline__ void in_mean_rstd(const float* stats, int b, int C, i
 template <typename T>
 __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
                                                        const T* __restrict__ res, T* __restrict__ y, const int64_t S,
-                                                       const int C, const int act, const int64_t yb16) {
+                                                       const int C, const int act, const int64_t yb16,
+                                                       uint8_t* __restrict__ mask) {
   const int ncg = C >> 3;
   const int b = blockIdx.y;
   const int64_t nvec = S * ncg;
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, 
   T* yblk = y + ((size_t)(cg >> 1) * yb16 + (size_t)b * S) * 16 + (cg & 1) * 8;
   y += base;
   if (res) res += base;
+  if (mask) mask += (size_t)b * nvec;   // one byte per 8-channel vector: bit e = (pre-activation value of channel e > 0)
   for (int64_t i = i0; i < nvec; i += stride) {
     float v[8];
     load8(x + i * 8, v);
@@ -120,6 +122,12 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, 
       load8(res + i * 8, r);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
+    if (mask) {
+      unsigned bits = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bits |= (v[e] > 0.f ? 1u : 0u) << e;
+      mask[i] = (uint8_t)bits;
     }
     if (act) {
 #pragma unroll
@@ -135,7 +143,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const T* __restrict__ y, const float* __restrict__ stats,
                                                             double* __restrict__ sums, const int64_t S, const int C,
-                                                            const int act, const int64_t rows_per_block) {
+                                                            const int act, const int64_t rows_per_block,
+                                                            const uint8_t* __restrict__ mask) {
   __shared__ double red[256 * 16];
   const int ncg = C >> 3;
   const int tid = threadIdx.x;
@@ -160,7 +169,11 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
       for (int e = 0; e < 8; ++e) xh[e] = (xv[e] - mean[e]) * rstd[e];
       if (act) {
-        if (y) {  // residual case: the activation saw xhat + residual, whose sign only y records
+        if (mask) {  // residual case with the forward's sign bits: one byte instead of a 16-byte vector of y
+          const unsigned bits = mask[((size_t)b * S + s) * ncg + cg];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] = ((bits >> e) & 1u) ? g[e] : g[e] * LRELU_SLOPE;
+        } else if (y) {  // residual case: the activation saw xhat + residual, whose sign only y records
           float yv[8];
           load8(y + off, yv);
 #pragma unroll
@@ -198,7 +211,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
                                                            const double* __restrict__ sums, T* __restrict__ dx,
                                                            T* __restrict__ dres, const int64_t S, const int C,
                                                            const int act, double* __restrict__ clear, const int clear_n,
-                                                           const int64_t dxb16) {
+                                                           const int64_t dxb16, const uint8_t* __restrict__ mask) {
   const int ncg = C >> 3;
   const int b = blockIdx.y;
   const int64_t nvec = S * ncg;
@@ -222,6 +235,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
   dx += base;
   if (y) y += base;
   if (dres) dres += base;
+  if (mask) mask += (size_t)b * nvec;
   for (int64_t i = i0; i < nvec; i += stride) {
     float g[8], xv[8], xh[8];
     load8(dy + i * 8, g);
@@ -229,7 +243,11 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) xh[e] = (xv[e] - mean[e]) * rstd[e];
     if (act) {
-      if (y) {
+      if (mask) {
+        const unsigned bits = mask[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = ((bits >> e) & 1u) ? g[e] : g[e] * LRELU_SLOPE;
+      } else if (y) {
         float yv[8];
         load8(y + i * 8, yv);
 #pragma unroll
@@ -308,7 +326,8 @@ extern "C" int ctu_in_finalize(int32_t B, int64_t S, int32_t C, double* acc, flo
 }
 
 extern "C" int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, const void* residual, void* y,
-                            int32_t B, int64_t S, int32_t C, int32_t act, int32_t y_layout, ctu_stream_t stream) {
+                            int32_t B, int64_t S, int32_t C, int32_t act, int32_t y_layout, uint8_t* sign_mask,
+                            ctu_stream_t stream) {
   if (int rc = check_in(x, B, S, C)) return rc;
   CTU_REQUIRE(stats && y, "null pointer");
   CTU_REQUIRE(y_layout == CTU_LAYOUT_NDHWC || (y_layout == CTU_LAYOUT_B16 && C % 16 == 0 && y != x), "in_apply: bad output layout");
@@ -317,30 +336,32 @@ extern "C" int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, 
   hipStream_t s = (hipStream_t)stream;
   CTU_DISPATCH(dtype,
                hipLaunchKernelGGL(in_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, stats,
-                                  (const float*)residual, (float*)y, S, C, act, yb16),
+                                  (const float*)residual, (float*)y, S, C, act, yb16, sign_mask),
                hipLaunchKernelGGL(in_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, stats,
-                                  (const bf16*)residual, (bf16*)y, S, C, act, yb16));
+                                  (const bf16*)residual, (bf16*)y, S, C, act, yb16, sign_mask));
   return ctu_check_launch("in_apply");
 }
 
 extern "C" int ctu_in_bwd_reduce(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
-                                 double* sums, int32_t B, int64_t S, int32_t C, int32_t act, ctu_stream_t stream) {
+                                 double* sums, int32_t B, int64_t S, int32_t C, int32_t act, const uint8_t* sign_mask,
+                                 ctu_stream_t stream) {
   if (int rc = check_in(x, B, S, C)) return rc;
-  CTU_REQUIRE(dy && stats && sums, "null pointer");  // y == NULL: no residual was added (sign taken from xhat)
+  CTU_REQUIRE(dy && stats && sums, "null pointer");  // y == NULL and no mask: no residual was added (sign taken from xhat)
   const int64_t rows = in_rows_per_block(S, B, C);
   dim3 grid((unsigned)((S + rows - 1) / rows), B);
   hipStream_t s = (hipStream_t)stream;
   CTU_DISPATCH(dtype,
                hipLaunchKernelGGL(in_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x,
-                                  (const float*)y, stats, sums, S, C, act, rows),
+                                  (const float*)y, stats, sums, S, C, act, rows, sign_mask),
                hipLaunchKernelGGL(in_bwd_reduce_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, (const bf16*)x,
-                                  (const bf16*)y, stats, sums, S, C, act, rows));
+                                  (const bf16*)y, stats, sums, S, C, act, rows, sign_mask));
   return ctu_check_launch("in_bwd_reduce");
 }
 
 extern "C" int ctu_in_bwd_apply(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
                                 const double* sums, void* dx, void* dres, int32_t B, int64_t S, int32_t C, int32_t act,
-                                double* clear_ws, int32_t clear_n, int32_t dx_layout, ctu_stream_t stream) {
+                                double* clear_ws, int32_t clear_n, int32_t dx_layout, const uint8_t* sign_mask,
+                                ctu_stream_t stream) {
   if (int rc = check_in(x, B, S, C)) return rc;
   CTU_REQUIRE(dy && stats && sums && dx, "null pointer");
   CTU_REQUIRE(dx_layout == CTU_LAYOUT_NDHWC || (dx_layout == CTU_LAYOUT_B16 && C % 16 == 0 && dx != dy && dx != x),
@@ -351,9 +372,9 @@ extern "C" int ctu_in_bwd_apply(ctu_dtype dtype, const void* dy, const void* x, 
   hipStream_t s = (hipStream_t)stream;
   CTU_DISPATCH(dtype,
                hipLaunchKernelGGL(in_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x,
-                                  (const float*)y, stats, sums, (float*)dx, (float*)dres, S, C, act, clear_ws, clear_n, dxb16),
+                                  (const float*)y, stats, sums, (float*)dx, (float*)dres, S, C, act, clear_ws, clear_n, dxb16, sign_mask),
                hipLaunchKernelGGL(in_bwd_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, (const bf16*)x,
-                                  (const bf16*)y, stats, sums, (bf16*)dx, (bf16*)dres, S, C, act, clear_ws, clear_n, dxb16));
+                                  (const bf16*)y, stats, sums, (bf16*)dx, (bf16*)dres, S, C, act, clear_ws, clear_n, dxb16, sign_mask));
   return ctu_check_launch("in_bwd_apply");
 }
 

@@ -977,6 +977,9 @@ def conv3d_cin1(x, weight, stride, padding):
 # ---------------------------------------------------------------------------------------------------------------
 # normalisation / activation
 # ---------------------------------------------------------------------------------------------------------------
+SIGN_MASK = not os.environ.get("CTU_NO_SIGN_MASK")
+
+
 class InstanceNormFn(torch.autograd.Function):
     """y = act(InstanceNorm3d(x) + residual), eps 1e-5, no affine, LeakyReLU(0.01)
     (resnet.py:97-124,156-157,198; hybrid_CTUNet.py:84-104)."""
@@ -1000,7 +1003,13 @@ class InstanceNormFn(torch.autograd.Function):
             call("ctu_in_stats", dc, ptr(x), B, S, C, ptr(acc), ptr(stats), stream())
         if out_b16 and (residual is not None or x.dtype != torch.bfloat16 or C % 16):
             raise RuntimeError("CTU_LAYOUT_B16 output: bf16, C % 16 == 0, no residual")
-        call("ctu_in_apply", dc, ptr(x), ptr(stats), ptr(residual), ptr(y), B, S, C, int(act), int(out_b16), stream())
+        # with a residual the LeakyReLU's argument sign survives only in y: record it as one byte per 8 channels, so the two
+        # backward kernels read 1/16 of the bytes a second and third pass over y would cost
+        mask = None
+        if SIGN_MASK and act and residual is not None and C % 8 == 0:
+            mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device)
+        call("ctu_in_apply", dc, ptr(x), ptr(stats), ptr(residual), ptr(y), B, S, C, int(act), int(out_b16), ptr(mask),
+             stream())
         # x is the output of a halo conv: its gradient has one reader, that conv's backward, which takes it blocked
         link = getattr(x, "_ctu_b16_link", None)
         ctx.dx_b16 = link is not None and x.dtype == torch.bfloat16 and C % 16 == 0 and ctx.needs_input_grad[0]
@@ -1009,13 +1018,17 @@ class InstanceNormFn(torch.autograd.Function):
             x._ctu_b16_link = None   # one norm per conv output: a second consumer would read a blocked gradient sum
         ctx.has_res = residual is not None
         # without a residual sign(y) == sign(xhat): backward recomputes the LeakyReLU mask from x and needs no y
-        ctx.save_for_backward(x, y if ctx.has_res else None, stats)
+        ctx.save_for_backward(x, (mask if mask is not None else y) if ctx.has_res else None, stats)
+        ctx.has_mask = mask is not None
         ctx.act = int(act)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, y, stats = ctx.saved_tensors
+        mask = None
+        if ctx.has_mask:
+            y, mask = None, y
         gy = gy.contiguous()
         B, C = x.shape[0], x.shape[-1]
         S = x.numel() // (B * C)
@@ -1028,9 +1041,9 @@ class InstanceNormFn(torch.autograd.Function):
         dc = dcode(x.dtype)
         # (measured: reducing and applying one batch item at a time, hoping the second read hits the 256 MB Infinity
         # Cache, is 2 % slower than one pass over the whole batch)
-        call("ctu_in_bwd_reduce", dc, ptr(gy), ptr(x), ptr(y), ptr(stats), ptr(sums), B, S, C, ctx.act, stream())
+        call("ctu_in_bwd_reduce", dc, ptr(gy), ptr(x), ptr(y), ptr(stats), ptr(sums), B, S, C, ctx.act, ptr(mask), stream())
         call("ctu_in_bwd_apply", dc, ptr(gy), ptr(x), ptr(y), ptr(stats), ptr(sums), ptr(gx), ptr(gres), B, S, C,
-             ctx.act, ptr(dirty), dirty_n, int(ctx.dx_b16), stream())
+             ctx.act, ptr(dirty), dirty_n, int(ctx.dx_b16), ptr(mask), stream())
         ws[3] ^= 1
         ws[4] = B * C * 2
         return gx, gres, None, None

@@ -202,19 +202,23 @@ int ctu_in_stats(ctu_dtype dtype, const void* x, int32_t B, int64_t S, int32_t C
  * handed back zeroed. */
 int ctu_in_finalize(int32_t B, int64_t S, int32_t C, double* acc, float* stats, ctu_stream_t stream);
 /* y_layout: ctu_layout of y (CTU_LAYOUT_B16 when the one consumer of y is ctu_conv3_halo; y must not alias x then). */
+/* sign_mask (optional, B*S*C/8 bytes): bit e of byte (voxel, C/8 group) = pre-activation value of channel 8 group + e > 0.
+ * With a residual the sign of the activation's argument is recorded nowhere else but in y; the backward kernels then read
+ * this byte instead of a 16-byte vector of y (twice). */
 int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, const void* residual, void* y, int32_t B,
-                 int64_t S, int32_t C, int32_t act, int32_t y_layout, ctu_stream_t stream);
+                 int64_t S, int32_t C, int32_t act, int32_t y_layout, uint8_t* sign_mask, ctu_stream_t stream);
 /* backward: g = dy * act'(y) (y may be NULL when no residual was added: then sign(y) == sign(xhat) and the third
- * input stream is skipped); sums[b][c] = (sum g, sum g*xhat), fp64, zero on entry;
+ * input stream is skipped; with sign_mask from ctu_in_apply, y is not read either); sums[b][c] = (sum g, sum g*xhat), fp64, zero on entry;
  * dx = rstd*(g - s1/S - xhat*s2/S); dres = g when dres != NULL.  ctu_in_bwd_apply also zeroes clear_ws[0..clear_n)
  * (optional, must differ from sums): pass the sums buffer of the PREVIOUS call on the stream so two buffers can
  * alternate without a memset launch.  dx_layout: ctu_layout of dx (CTU_LAYOUT_B16 when x is the output of a
  * ctu_conv3_halo convolution, whose data- and weight-gradient kernels are the only readers of dx). */
 int ctu_in_bwd_reduce(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
-                      double* sums, int32_t B, int64_t S, int32_t C, int32_t act, ctu_stream_t stream);
+                      double* sums, int32_t B, int64_t S, int32_t C, int32_t act, const uint8_t* sign_mask,
+                      ctu_stream_t stream);
 int ctu_in_bwd_apply(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
                      const double* sums, void* dx, void* dres, int32_t B, int64_t S, int32_t C, int32_t act,
-                     double* clear_ws, int32_t clear_n, int32_t dx_layout, ctu_stream_t stream);
+                     double* clear_ws, int32_t clear_n, int32_t dx_layout, const uint8_t* sign_mask, ctu_stream_t stream);
 
 /* K8 LayerNorm (eps 1e-5, affine) (vit.py:35,55,116,118; hybrid_CTUNet.py:456,518,630-631).
  * x,y: [rows][dim]; mean_rstd: fp32 [rows][2]; dgamma/dbeta: fp32 [dim], accumulated (atomics). */

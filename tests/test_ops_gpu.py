@@ -652,3 +652,29 @@ def test_conv3d_halo_long_weight_stages_bit_equal(ops, case):
             _lib.call("ctu_set_option", b"route", 0)
     a, b = run(0), run(16)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_instance_norm_sign_mask_equals_reading_y(ops, dtype):
+    """With a residual, the backward kernels take the LeakyReLU mask from the byte-per-8-channels sign mask the forward wrote
+    (ops.SIGN_MASK) instead of re-reading y: same gradients, bit for bit (the mask records sign(pre-activation), y > 0 says
+    the same thing)."""
+    B, D, H, W, C = 2, 6, 7, 9, 64
+    x0 = cl(rnd((B, C, D, H, W), 31, 2.0) + 0.2).to(dtype).cuda()
+    r0 = cl(rnd((B, C, D, H, W), 32)).to(dtype).cuda()
+    gy = cl(rnd((B, C, D, H, W), 33)).to(dtype).cuda()
+
+    def run(flag):
+        ops.SIGN_MASK = flag
+        try:
+            x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+            y = ops.instance_norm(x, r, True)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            return y.detach().clone(), x.grad.clone(), r.grad.clone()
+        finally:
+            ops.SIGN_MASK = True
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    assert (a[1].float() - b[1].float()).abs().max() <= 1e-2 * b[1].float().abs().max()   # fp64 atomics order in the sums
+    assert (a[1] == b[1]).float().mean() > 0.99

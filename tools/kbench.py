@@ -93,7 +93,7 @@ def inorm(B, D, H, W, C, sets=3):
 
     def f_apply():
         i = nxt()
-        call("ctu_in_apply", dcode(DT), ptr(xs[i]), ptr(stats), None, ptr(ys[i]), B, S, C, 1, LAYOUT, stream())
+        call("ctu_in_apply", dcode(DT), ptr(xs[i]), ptr(stats), None, ptr(ys[i]), B, S, C, 1, LAYOUT, None, stream())
 
     def f_stats():
         i = nxt()
@@ -101,12 +101,12 @@ def inorm(B, D, H, W, C, sets=3):
 
     def f_red():
         i = nxt()
-        call("ctu_in_bwd_reduce", dcode(DT), ptr(gs[i]), ptr(xs[i]), None, ptr(stats), ptr(sums), B, S, C, 1, stream())
+        call("ctu_in_bwd_reduce", dcode(DT), ptr(gs[i]), ptr(xs[i]), None, ptr(stats), ptr(sums), B, S, C, 1, None, stream())
 
     def f_bapply():
         i = nxt()
         call("ctu_in_bwd_apply", dcode(DT), ptr(gs[i]), ptr(xs[i]), None, ptr(stats), ptr(sums), ptr(ys[i]), None, B, S, C, 1,
-             ptr(dirty), B * C * 2, LAYOUT, stream())
+             ptr(dirty), B * C * 2, LAYOUT, None, stream())
     tag = f"{C}ch @{D}x{H}x{W} B{B}"
     report(f"in_apply       {tag}", timeit(f_apply), 0, 2 * nb)
     report(f"in_bwd_reduce  {tag}", timeit(f_red), 0, 2 * nb)
