@@ -235,7 +235,11 @@ __device__ __forceinline__ void halo_row_to_hw(int row, int& hh, int& ww) {
 // cycles it spends (0) before its first stage barrier opens, (1) waiting at stage barriers (own DMA wait + s_barrier),
 // (2) between barriers (fragment reads + MFMAs + DMA issue), (3) in the epilogue, and writes the four sums to
 // stamps[workgroup][wave][4] - memory nothing else reads (MI355X_MICROARCH.md, in-kernel stamps).
-template <int NT, int RD = (NT <= 2 ? 2 : 3), int TPS = 3, bool STAMP = false>
+// HSP = gather pieces per weight-loader wave (waves 1 - 3); wave 0 keeps the other 19 - 3 HSP.  HSP = 0: wave 0 gathers alone (the
+// rule above).  HSP > 0 deals the burst over all four waves so that no wave reaches the next barriers later than the others by a
+// whole gather; a loader wave issues its pieces AFTER the weight stage of the same barrier, and for the RD - 1 barriers that follow
+// the pieces are younger than the awaited weights: those waits leave HSP more operations in flight (counted, not vmcnt(0)).
+template <int NT, int RD = (NT <= 2 ? 2 : 3), int TPS = 3, bool STAMP = false, int HSP = 4>
 __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo_dma_kernel(const HaloArgs p) {
   unsigned long long st_t0 = 0, st_wait = 0, st_work = 0, st_pro = 0, st_mark = 0;
   if (STAMP) st_t0 = st_mark = __builtin_amdgcn_s_memtime();
@@ -274,12 +278,16 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
   // of the kernel at 128 -> 128 @ 48 x 48 x 96, 37 % at 64 -> 64 @ 96^3).  So wave 0 issues ALL halo instructions and
   // nothing else - its one wait (vmcnt(0) at the first stage of a chunk) sees a prefetch that is nine stages old - and
   // waves 1 - 3 issue the weight stages.
-  // per-lane halo sources of wave 0's DMA instructions (instruction k fills slots 64 k ..)
-  int hm[HINS];
+  // per-lane halo sources of this wave's gather instructions (piece k fills slots 64 k ..; this wave owns pieces kbase + j)
+  constexpr int HP0 = HINS - 3 * HSP;          // pieces of wave 0
+  constexpr int HPM = HP0 > HSP ? HP0 : HSP;
+  static_assert(HP0 >= 1, "wave 0 keeps at least one gather piece");
+  const int kbase = wave == 0 ? 0 : HP0 + (wave - 1) * HSP;
+  int hm[HPM];
   unsigned hpart = 0;
 #pragma unroll
-  for (int k = 0; k < HINS; ++k) {
-    const int S = k * 64 + lane;
+  for (int k = 0; k < HPM; ++k) {
+    const int S = (kbase + k) * 64 + lane;
     int m = -1;
     if (S < 2 * HALO_VOX) {
       const int vox = S >> 1, hs = S & 1;
@@ -294,8 +302,8 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
   }
   constexpr int BW = SFR / 3;  // weight DMA instructions per loader wave (1 - 3) and stage: NT (3-tap stages), 3 NT (9-tap)
 
-  // gather pieces [k0, k1) of half chunk hc (wave 0 only; k0, k1 wave-uniform, hm[] keeps static indices)
-  auto issue_halo = [&](int hc, int k0, int k1) {
+  // this wave's gather pieces of half chunk hc (hm[] keeps static indices)
+  auto issue_halo = [&](int hc) {
     if (p.debug & 8) return;
     const int c0 = hc * 16;
     const bool first = c0 < p.C1;
@@ -304,9 +312,10 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
     const int cc = first ? c0 : c0 - p.C1;
     src += first ? (size_t)(cc >> 4) * p.bs1 : (size_t)cc;
     unsigned char* dst = smem + (hc & 1) * HBUF;
+    dst += kbase * 1024;
 #pragma unroll
-    for (int k = 0; k < HINS; ++k) {
-      if (k >= k0 && k < k1) {
+    for (int k = 0; k < HPM; ++k) {
+      if (wave == 0 ? k < HP0 : k < HSP) {
         const bf16* g = hm[k] >= 0 ? src + (size_t)hm[k] * vs + ((hpart >> k) & 1) * 8
                                    : reinterpret_cast<const bf16*>(g_zero16);
         dma16(g, dst + k * 1024);
@@ -352,11 +361,13 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
   halo_row_to_hw(r, vrow, vcol);
 
   if (wave == 0) {
-    issue_halo(hc_b, 0, HINS);
+    issue_halo(hc_b);
   } else {
+    if (HSP > 0) issue_halo(hc_b);  // older than every weight stage: the first weight wait covers it
     issue_b(hc_b, 0, 0);
     if (RD == 3) issue_b(hc_b, 1, 1);
   }
+  int hyoung = 0;  // loader waves: barriers to come at which the last gather is younger than the awaited weights
   int hc = hc_b, s = 0, rs = 0;               // stage being computed: half chunk, (td, th) index, ring slot
   int ihc = hc_b, is = RD - 1, irs = RD - 1;  // stage being fetched (RD - 1 ahead)
   for (int u = 0; u < U; ++u) {
@@ -372,11 +383,20 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
       // the next half chunk's 19 gather pieces go out in ONE burst, into the buffer whose last readers passed this barrier
       // (dealt out three per stage, or one per tap behind the MFMAs, this wave reaches more barriers late and every wave
       // waits longer: +3.5 % / +10 % kernel time)
-      if (s == 0 && hc + 1 < HC) issue_halo(hc + 1, 0, HINS);
+      if (s == 0 && hc + 1 < HC) issue_halo(hc + 1);
     } else {
-      // own weight DMAs of this stage have landed; still in flight: the RD - 2 younger stages
-      wait_vm_then_barrier<(RD - 2) * BW>();
+      // own weight DMAs of this stage have landed; still in flight: the RD - 2 younger stages (and a younger gather)
+      if (HSP > 0 && hyoung > 0) {
+        wait_vm_then_barrier<(RD - 2) * BW + HSP>();
+        --hyoung;
+      } else {
+        wait_vm_then_barrier<(RD - 2) * BW>();
+      }
       issue_b(ihc, is, irs);  // past the end: refetches the last stage into a slot nobody reads (keeps the counts)
+      if (HSP > 0 && s == 0 && hc + 1 < HC) {  // (behind the MFMAs of this stage instead: no better, r41 in profiles/)
+        issue_halo(hc + 1);
+        hyoung = (p.debug & 8) ? 0 : RD - 1;
+      }
     }
     if (STAMP) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -601,15 +621,19 @@ template <> struct HaloDma<bf16> {
     const dim3 grid(bricks, ntn / NT, ksplit);
     if ((q.debug & 16) && ksplit == 1 && ws && ws_floats >= (int64_t)grid.x * grid.y * 32 && NT >= 2) {   // diagnostic build
       q.part_stamps = ws;
-      if (NT == 4) hipLaunchKernelGGL((conv3_halo_dma_kernel<4, 3, 3, true>), grid, dim3(256), 0, s, q);
-      else hipLaunchKernelGGL((conv3_halo_dma_kernel<2, 2, 3, true>), grid, dim3(256), 0, s, q);
+      if (NT == 4) hipLaunchKernelGGL((conv3_halo_dma_kernel<4, 3, 3, true, 4>), grid, dim3(256), 0, s, q);
+      else hipLaunchKernelGGL((conv3_halo_dma_kernel<2, 2, 3, true, 4>), grid, dim3(256), 0, s, q);
       return true;
     }
     const bool long_stages = (ctu_option_route() & CTU_ROUTE_HALO_TPS9) != 0;
-    if (NT == 4) hipLaunchKernelGGL(conv3_halo_dma_kernel<4>, grid, dim3(256), 0, s, q);
-    else if (NT == 2 && long_stages) hipLaunchKernelGGL((conv3_halo_dma_kernel<2, 2, 9>), grid, dim3(256), 0, s, q);
+    const bool alone = (ctu_option_route() & CTU_ROUTE_HALO_GATHER_WAVE0) != 0;  // previous rule: wave 0 gathers the halo alone
+    if (NT == 4 && alone) hipLaunchKernelGGL((conv3_halo_dma_kernel<4, 3, 3, false, 0>), grid, dim3(256), 0, s, q);
+    else if (NT == 4) hipLaunchKernelGGL(conv3_halo_dma_kernel<4>, grid, dim3(256), 0, s, q);
+    else if (NT == 2 && long_stages) hipLaunchKernelGGL((conv3_halo_dma_kernel<2, 2, 9, false, 0>), grid, dim3(256), 0, s, q);
+    else if (NT == 2 && alone) hipLaunchKernelGGL((conv3_halo_dma_kernel<2, 2, 3, false, 0>), grid, dim3(256), 0, s, q);
     else if (NT == 2) hipLaunchKernelGGL(conv3_halo_dma_kernel<2>, grid, dim3(256), 0, s, q);
-    else if (long_stages) hipLaunchKernelGGL((conv3_halo_dma_kernel<1, 2, 9>), grid, dim3(256), 0, s, q);
+    else if (long_stages) hipLaunchKernelGGL((conv3_halo_dma_kernel<1, 2, 9, false, 0>), grid, dim3(256), 0, s, q);
+    else if (alone) hipLaunchKernelGGL((conv3_halo_dma_kernel<1, 2, 3, false, 0>), grid, dim3(256), 0, s, q);
     else hipLaunchKernelGGL(conv3_halo_dma_kernel<1>, grid, dim3(256), 0, s, q);
     if (ksplit > 1) {
       const int64_t S = (int64_t)p.D * p.H * p.W;

@@ -49,7 +49,8 @@ const char* ctu_last_error(void);
  * kernels apply; "generic_gemm" = 1 keeps plain bf16 GEMMs on the generic implicit-GEMM kernels instead of the LDS-DMA
  * GEMM kernels - so both implementations can be checked against the oracle in one process.  "route" = bit set of A/B
  * routing switches for measurements (1: short-K layers on the general NT kernel instead of gemm_nt_stream, 2: no 128-deep
- * stages, 4: no two-k-group trunk tiles, 8: previous channel-split rule of the small 3x3x3 convs); "nt_debug" = bits
+ * stages, 4: no two-k-group trunk tiles, 8: previous channel-split rule of the small 3x3x3 convs, 16: 9-tap weight stages
+ * in the halo kernels, 32: wave 0 gathers the halo alone); "nt_debug" = bits
  * that switch a kernel's memory traffic off for timing.  Options are plain process-wide ints read per launch - no
  * launch path calls getenv. */
 int ctu_set_option(const char* name, int32_t value);

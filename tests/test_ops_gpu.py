@@ -654,6 +654,35 @@ def test_conv3d_halo_long_weight_stages_bit_equal(ops, case):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
+@pytest.mark.parametrize("route", [32])
+@pytest.mark.parametrize("case", [(2, 8, 16, 16, 64, 64), (1, 5, 9, 11, 128, 128), (2, 4, 8, 8, 96, 64), (1, 9, 17, 10, 64, 256),
+                                  (1, 6, 9, 9, 64, 32)])
+def test_conv3d_halo_spread_gather_bit_equal(ops, case, route):
+    """The halo gather of the LDS-DMA kernels is dealt over all four waves (7 + 3 x 4 pieces, counted vmcnt waits on the
+    weight-loader waves); ctu_set_option("route", 32) restores the rule it replaced (wave 0 issues all 19 pieces).  Same LDS image,
+    same products: forward output and data gradient must be bit-equal (ragged volumes, one / two / four n tiles per workgroup,
+    several half chunks)."""
+    from hybrid_ctunet_amd import _lib
+    B, D, H, W, C, N = case
+    x0 = rnd((B, D, H, W, C), 41).to(torch.bfloat16).cuda()
+    w = torch.nn.Parameter(rnd((N, C, 3, 3, 3), 42, 1 / math.sqrt(27 * C)).float().cuda())
+    gout = rnd((B, D, H, W, N), 43).to(torch.bfloat16).cuda()
+
+    def run(rt):
+        _lib.call("ctu_set_option", b"route", rt)
+        try:
+            x = x0.clone().requires_grad_(True)
+            w.grad = None
+            y = ops.conv3d(x, w, 1, 1)
+            y.backward(gout)
+            torch.cuda.synchronize()
+            return y.detach().clone(), x.grad.clone()
+        finally:
+            _lib.call("ctu_set_option", b"route", 0)
+    a, b = run(0), run(route)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_instance_norm_sign_mask_equals_reading_y(ops, dtype):
     """With a residual, the backward kernels take the LeakyReLU mask from the byte-per-8-channels sign mask the forward wrote
