@@ -52,7 +52,7 @@ class KernelTimer:
             self.rec.append((name, 2.0 * B * D * H * W * N * (C1 + C2) * 27, e0, e1))
             self.shape[len(self.rec) - 1] = f"conv3_halo {C1}+{C2}->{N} @{D}x{H}x{W} B{B}"
             return
-        if name == "ctu_conv3_halo_wgrad":  # (dtype, dy, x1, x2, dw, B, D, H, W, C1, C2, N, stream)
+        if name == "ctu_conv3_halo_wgrad":  # (dtype, dy, x1, x2, dw, B, D, H, W, C1, C2, N, layouts, ws, ws_floats, stream)
             B, D, H, W, C1, C2, N = args[5:12]
             self.rec.append((name, 2.0 * B * D * H * W * N * (C1 + C2) * 27, e0, e1))
             self.shape[len(self.rec) - 1] = f"conv3_halo_wgrad {C1}+{C2}->{N} @{D}x{H}x{W} B{B}"
@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (train.GraphedStep).  Off by default: on ROCm 7.2 the graph executor "
                          "serialises the captured streams (58 ms / step against 49 ms enqueued eagerly on four streams)")
+    ap.add_argument("--route", type=int, default=0,
+                    help="A/B measurements: ctu_set_option(\"route\", N) bit set (include/ctunet_hip.h); 0 = the shipped routing")
     ap.add_argument("--serial", action="store_true",
                     help="one HIP stream (no branch / weight-gradient overlap): per-kernel profiles without co-running kernels")
     a = ap.parse_args()
@@ -199,6 +201,8 @@ def main():
     from hybrid_ctunet_amd import _lib
     from hybrid_ctunet_amd.synthetic import synthetic_batch
 
+    if a.route:
+        _lib.call("ctu_set_option", b"route", a.route)
     torch.manual_seed(0)  # identical default init on every rank (and DataParallel broadcasts rank 0 anyway)
     model = H.build_model(a.model).to(dev)
     n_params = sum(p.numel() for p in model.parameters())
@@ -330,7 +334,7 @@ def main():
             "config": {"workload": f"{a.model} d101 pf8, per-GPU batch {a.batch} x 1x96x96x96, fwd + DiceCE "
                                    f"(deep supervision, on-device targets) + bwd + fused AdamW"
                                    + (" + RCCL bucketed grad all-reduce" if world > 1 else ""),
-                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "launch": graph_note,
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "launch": graph_note, **({"route": a.route} if a.route else {}),
                        "params_M": round(n_params / 1e6, 2),
                        "final_loss": round(final_loss, 5)},
             "whole_path_tflops_per_gpu": round(whole_path, 2),

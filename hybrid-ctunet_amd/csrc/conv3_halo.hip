@@ -713,7 +713,9 @@ struct HaloWgArgs {
   int nbd, nbh, nbw, nbricks, bricks_per_block, tiles_c, tiles_n;
   int xvs, yvs;      // voxel strides of x1 and dy (bf16 DMA kernel), see HaloArgs::vs1
   int64_t xbs, ybs;  // 16-channel-block strides
-  int debug;  // measurement hook (ctu_set_option "nt_debug"): 4 = no operand DMA
+  float* part;  // [splits][27][N][K] partial panels (workspace) or null: atomics straight into dw
+  void* stamps; // STAMP build only
+  int debug;  // measurement hook (ctu_set_option "nt_debug"): 4 = no operand DMA, 1 = no epilogue
 };
 
 template <typename T>
@@ -839,21 +841,29 @@ __global__ __launch_bounds__(256) void conv3_halo_wgrad_kernel(const HaloWgArgs 
 // Workgroups that walk the same brick range (all tiles of one split) are placed on one XCD so that the halo / dY
 // bytes they share are served by that XCD's L2.
 // ---------------------------------------------------------------------------------------------------------
-template <int NTN>
+// STAMP (diagnostic build, ctu_set_option("nt_debug", 16); never launched by the product): every wave sums the clock ticks it
+// spends (0) until its first operands have landed, (1) waiting for its own DMA at later brick barriers, (2) at the barriers
+// themselves, (3) in the k loops, (4) in the epilogue, and writes them to stamps[workgroup][wave][8].
+template <int NTN, bool BURST = false, bool STAMP = false>
 __global__ __launch_bounds__(512, 1) void conv3_halo_wgrad_dma_kernel(const HaloWgArgs p) {
+  unsigned long long st_v[5] = {0, 0, 0, 0, 0}, st_mark = 0, st_c0 = 0, st_r0 = 0;
+  if (STAMP) {
+    st_c0 = st_mark = __builtin_amdgcn_s_memtime();
+    st_r0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz: (memtime ticks) / (memrealtime ticks) x 0.1 = shader clock in GHz
+  }
   constexpr int HINS = 38;              // DMA wave-instructions per halo chunk: 600 voxels x 4 slots = 2400 <= 2432
   constexpr int HBYTES = HINS * 1024;
   constexpr int YBYTES = 256 * 64;      // dY tile of one 32-wide n tile
   constexpr int BUF = HBYTES + NTN * YBYTES;
-  constexpr int NI = NTN == 2 ? 7 : 4;  // accumulator tiles per wave
-  constexpr int TS = NTN == 2 ? 4 : 8;  // tap stride between them
+  constexpr int ROWS = NTN == 2 ? 2 : 1;  // whole (td, th) rows of three taps per wave
+  constexpr int NI = 3 * ROWS + 1;        // accumulator tiles per wave: the rows' taps + one tap of row (2, 2)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = NTN == 2 ? (wave & 1) : 0;
-  const int t0 = NTN == 2 ? (wave >> 1) : wave;
+  const int tg = NTN == 2 ? (wave >> 1) : wave;  // tap group: rows ROWS tg .. and, for tg < 3, tap (2, 2, tg)
   const int vid = xcd_remap(blockIdx.x, gridDim.x);
   const int tiles = p.tiles_n * p.tiles_c;
   const int tile = vid % tiles, split = vid / tiles;
@@ -879,36 +889,42 @@ __global__ __launch_bounds__(512, 1) void conv3_halo_wgrad_dma_kernel(const Halo
     hv[k] = S < 4 * HALO_VOX ? (hd | (hh << 4) | (hw << 8) | ((S & 3) << 12)) : -1;
   }
 
-  auto issue = [&](int brick, int buf) {
-    if (p.debug & 4) return;
+  // operand DMA of one brick = NP pieces per wave (5 halo + 2 NTN dY instructions); piece q is a compile-time index
+  constexpr int NP = 5 + 2 * NTN;
+  struct BrickAt { int b, d0, h0, w0; };
+  auto locate = [&](int brick) {
+    BrickAt a;
     int t = brick;
     const int bw = t % p.nbw; t /= p.nbw;
     const int bh = t % p.nbh; t /= p.nbh;
     const int bd = t % p.nbd;
-    const int b = t / p.nbd;
-    const int d0 = bd * HB_D, h0 = bh * HB_H, w0 = bw * HB_W;
+    a.b = t / p.nbd;
+    a.d0 = bd * HB_D; a.h0 = bh * HB_H; a.w0 = bw * HB_W;
+    return a;
+  };
+  auto issue_piece = [&](const BrickAt& a, int buf, int q) {
+    if (p.debug & 4) return;
     unsigned char* dst = smem + buf * BUF;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
+    if (q < 5) {
+      const int k = q;
       const int i = wave + 8 * k;
       if (i < HINS) {
-        const int gd = d0 + (hv[k] & 15) - 1, gh = h0 + ((hv[k] >> 4) & 15) - 1, gw = w0 + ((hv[k] >> 8) & 15) - 1;
+        const int gd = a.d0 + (hv[k] & 15) - 1, gh = a.h0 + ((hv[k] >> 4) & 15) - 1, gw = a.w0 + ((hv[k] >> 8) & 15) - 1;
         const bool ok = hv[k] >= 0 && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
                         (unsigned)gw < (unsigned)p.W;
-        const int m = ((b * p.D + gd) * p.H + gh) * p.W + gw;
+        const int m = ((a.b * p.D + gd) * p.H + gh) * p.W + gw;
         const int ch = cc + ((hv[k] >> 12) & 3) * 8;  // first of this lane's 8 channels
         dma16(ok ? src + (size_t)m * cs + (size_t)(ch >> 4) * cbs + (ch & 15) : zero, dst + i * 1024);
       }
-    }
-#pragma unroll
-    for (int k = 0; k < 2 * NTN; ++k) {
+    } else {
+      const int k = q - 5;
       const int j = wave + 8 * k;  // < 16 NTN
       const int S = (j & 15) * 64 + lane;
       const int vox = S >> 2;
-      const int gd = d0 + (vox >> 6), gh = h0 + ((vox >> 3) & 7), gw = w0 + (vox & 7);
+      const int gd = a.d0 + (vox >> 6), gh = a.h0 + ((vox >> 3) & 7), gw = a.w0 + (vox & 7);
       const int n = n0 + (j >> 4) * 32 + (S & 3) * 8;
       const bool ok = gd < p.D && gh < p.H && gw < p.W && n < p.N;
-      const int m = ((b * p.D + gd) * p.H + gh) * p.W + gw;
+      const int m = ((a.b * p.D + gd) * p.H + gh) * p.W + gw;
       dma16(ok ? dy + (size_t)m * p.yvs + (size_t)(n >> 4) * p.ybs + (n & 15) : zero, dst + HBYTES + j * 1024);
     }
   };
@@ -918,42 +934,144 @@ __global__ __launch_bounds__(512, 1) void conv3_halo_wgrad_dma_kernel(const Halo
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-  // halo element offset of each owned tap (+ this lane's channel); a wave with one tap fewer repeats tap 26 into an
-  // accumulator that is never written back - it would only wait at the brick barrier otherwise, and the k loop stays
-  // free of branches
-  int tapoff[NI];
+  // Taps: a wave owns whole (td, th) rows.  The three taps of a row read the same ten halo voxels along w, shifted by one: they
+  // are fetched ONCE (three transposed reads: voxels 0-3, 4-7, 8-11 of this lane's channel) and the fragments of tw = 0, 1, 2 are
+  // cut from those registers (tw = 1 with four v_alignbit) - 10 LDS reads per k step and wave instead of 16.  With one read pair
+  // per tap the k loop was bound by LDS bandwidth (8 fragments per 7 MFMAs: 146 B/clk/CU asked at full matrix rate, 128 there).
+  // Row (2, 2) is dealt out tap by tap to groups 0 - 2; the group without one repeats a tap into an accumulator never written.
+  int rowoff[ROWS];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int tap = min(t0 + TS * i, 26);
-    const int tw = tap % 3, tq = tap / 3;
-    const int th = tq % 3, td = tq / 3;
-    tapoff[i] = ((td * HALO_H + th) * HALO_W + tw) * 32 + r;
+  for (int j = 0; j < ROWS; ++j) {
+    const int R = ROWS * tg + j, td = R / 3, th = R - 3 * td;
+    rowoff[j] = ((td * HALO_H + th) * HALO_W) * 32 + r;
   }
+  const int singleoff = ((2 * HALO_H + 2) * HALO_W + (tg < 3 ? tg : 2)) * 32 + r;
+  auto tap_of = [&](int i) { return i < 3 * ROWS ? (ROWS * tg + i / 3) * 3 + i % 3 : (tg < 3 ? 24 + tg : -1); };
 
   const int brick_begin = split * p.bricks_per_block;
   const int brick_end = min(p.nbricks, brick_begin + p.bricks_per_block);
-  if (brick_begin < brick_end) issue(brick_begin, 0);
+  if (brick_begin < brick_end) {
+    const BrickAt a = locate(brick_begin);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) issue_piece(a, 0, q);
+  }
   int buf = 0;
   for (int brick = brick_begin; brick < brick_end; ++brick, buf ^= 1) {
     // this brick's DMAs (issued one compute phase ago) have landed in every wave, and every wave is done reading
     // the other buffer
+    if (STAMP) {
+      unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (brick > brick_begin) st_v[3] += t - st_mark;
+      st_mark = t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      t = __builtin_amdgcn_s_memtime();
+      st_v[brick > brick_begin ? 1 : 0] += t - st_mark;
+      st_mark = t;
+      asm volatile("s_barrier" ::: "memory");
+      t = __builtin_amdgcn_s_memtime();
+      st_v[2] += t - st_mark;
+      st_mark = t;
+    } else
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (brick + 1 < brick_end) issue(brick + 1, buf ^ 1);
+    // the next brick's pieces go out one per k step, between the MFMAs (in one burst behind the barrier, all eight waves spend
+    // ~10 % of the brick on address arithmetic with the matrix pipe idle)
+    const bool more = brick + 1 < brick_end;
+    const BrickAt an = locate(more ? brick + 1 : brick);
     const bf16* halo = reinterpret_cast<const bf16*>(smem + buf * BUF);
     const bf16* dyt = reinterpret_cast<const bf16*>(smem + buf * BUF + HBYTES + nt * YBYTES);
-#pragma unroll 2
-    for (int s = 0; s < 16; ++s) {
+    // k loop, software pipelined by hand: the LDS reads of step s + 1 are issued before the MFMAs of step s (hipcc alone puts each
+    // read right in front of its use - a wave then runs ~55 % of the time and the SIMD's second wave has to fill the rest)
+    bf16x8 fa[2], fs[2];
+    unsigned rw[2][ROWS][5];
+    auto fetch = [&](int s, int slot) {
       const int d = s >> 2, hh = 2 * (s & 3) + h;  // this lane half's row of 8 voxels along w
-      const bf16x8 fa = Mma<bf16>::gather(&dyt[(d * 64 + hh * 8) * 32 + r], 32);
+      const int vb = ((d * HALO_H + hh) * HALO_W) * 32;
+      fa[slot] = Mma<bf16>::gather(&dyt[(d * 64 + hh * 8) * 32 + r], 32);
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
-        Mma<bf16>::mma(fa, Mma<bf16>::gather(&halo[tapoff[i] + ((d * HALO_H + hh) * HALO_W) * 32], 32), acc[i]);
+      for (int j = 0; j < ROWS; ++j) Mma<bf16>::row3_fetch(&halo[rowoff[j] + vb], 32, rw[slot][j]);
+      fs[slot] = Mma<bf16>::gather(&halo[singleoff + vb], 32);
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < 16) fetch(s + 1, cur ^ 1);
+      if (BURST ? s == 0 : s < NP) {
+        if (more) {
+          if (BURST) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) issue_piece(an, buf ^ 1, q);
+          } else {
+            issue_piece(an, buf ^ 1, s);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < ROWS; ++j) {
+        bf16x8 f0, f1, f2;
+        Mma<bf16>::row3_frags(rw[cur][j], f0, f1, f2);
+        Mma<bf16>::mma(fa[cur], f0, acc[3 * j]);
+        Mma<bf16>::mma(fa[cur], f1, acc[3 * j + 1]);
+        Mma<bf16>::mma(fa[cur], f2, acc[3 * j + 2]);
+      }
+      Mma<bf16>::mma(fa[cur], fs[cur], acc[3 * ROWS]);
+      __builtin_amdgcn_sched_barrier(0);
     }
+  }
+  if (STAMP) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    st_v[3] += t - st_mark;
+    st_mark = t;
+  }
+  if (p.debug & 1) return;
+  if (p.part) {
+    // 16 one-dword stores per tile and lane are bound by the store instruction rate (6.9 K wave instructions per CU: ~60 us for
+    // 64 -> 64 @ 96^3); through a per-wave LDS tile each lane stores four float4 instead, 128-B rows contiguous over 8 lanes
+    __syncthreads();  // all waves are done reading the operand buffers
+    constexpr int SLD = 36;
+    float* st = reinterpret_cast<float*>(smem) + wave * 32 * SLD;
+    float* dst = p.part + (size_t)split * 27 * p.N * K;
+    const int srow = lane >> 3, scol = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int tap = tap_of(i);
+      if (tap >= 0) {  // wave-uniform
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[((e & 3) + 8 * (e >> 2) + 4 * h) * SLD + r] = acc[i][e];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = 8 * q + srow;
+          const int n = n0 + nt * 32 + row, c = c0 + scol;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&st[row * SLD + scol]);
+          // (streaming "nt" and write-through "sc0 sc1" stores: same kernel time, r60 / r61 in profiles/)
+          if (n < p.N && c < K) *reinterpret_cast<f32x4*>(&dst[((size_t)tap * p.N + n) * K + c]) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    if (STAMP && lane == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned long long* d = reinterpret_cast<unsigned long long*>(p.stamps) + ((size_t)blockIdx.x * 8 + wave) * 8;
+      const unsigned long long tc = __builtin_amdgcn_s_memtime();
+      st_v[4] = tc - st_mark;
+#pragma unroll
+      for (int e = 0; e < 5; ++e) d[e] = st_v[e];
+      d[5] = tc - st_c0;
+      const unsigned long long tr = __builtin_amdgcn_s_memrealtime();
+      d[6] = tr - st_r0;
+      d[7] = st_r0;  // start on the 100 MHz clock all CUs share: dispatch stagger
+
+    }
+    return;
   }
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int tap = t0 + TS * i;
-    if (tap < 27) {
+    const int tap = tap_of(i);
+    if (tap >= 0) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int n = n0 + nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -964,15 +1082,50 @@ __global__ __launch_bounds__(512, 1) void conv3_halo_wgrad_dma_kernel(const Halo
   }
 }
 
+// dw[i] += sum over splits of part[s][i].  Block = 64 element lanes (VEC floats each) x 4 split lanes: split lane g sums the
+// partial panels g, g + 4, ..., the four sums meet in LDS and lane g = 0 adds the result into dw - no atomics (a grid that split the
+// partial panels over workgroups and combined them with atomics took 18 - 27 us for 57 MB, this takes the 11 us of the bytes).
+// VEC = 1 for the small panels keeps >= 400 workgroups in flight.
+template <int VEC>
+__global__ __launch_bounds__(256) void halo_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                 const int64_t panel, const int splits) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  __shared__ float red[3][64][VEC];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t i = ((int64_t)blockIdx.x * 64 + lane) * VEC;
+  vec_t a = 0.f;
+  if (i < panel) {
+    const float* src = part + i;
+#pragma unroll 8
+    for (int sp = g; sp < splits; sp += 4) a += *reinterpret_cast<const vec_t*>(src + (int64_t)sp * panel);
+  }
+  if (g > 0) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[g - 1][lane][e] = a[e];
+  }
+  __syncthreads();
+  if (g == 0 && i < panel) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) a[e] += red[0][lane][e] + red[1][lane][e] + red[2][lane][e];
+    vec_t d = *reinterpret_cast<const vec_t*>(dw + i);
+    d += a;
+    *reinterpret_cast<vec_t*>(dw + i) = d;
+  }
+}
+
 extern "C" int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void* x1, const void* x2, float* dw, int32_t B,
                                     int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N,
-                                    int32_t x1_layout, int32_t dy_layout, ctu_stream_t stream) {
+                                    int32_t x1_layout, int32_t dy_layout, float* ws, int64_t ws_floats,
+                                    ctu_stream_t stream) {
   CTU_REQUIRE(dy && x1 && dw, "conv3_halo_wgrad: null pointer");
+  CTU_REQUIRE(ws_floats >= 0 && (ws_floats == 0 || ws), "conv3_halo_wgrad: bad workspace");
   CTU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3_halo_wgrad: bad dims");
   CTU_REQUIRE(C1 > 0 && C1 % 32 == 0 && C2 >= 0 && C2 % 32 == 0 && (C2 == 0 || x2), "conv3_halo_wgrad: C1, C2 %% 32");
   CTU_REQUIRE(N > 0 && N % 8 == 0, "conv3_halo_wgrad: N %% 8");
   HaloWgArgs p;
   p.debug = ctu_option_nt_debug();
+  p.part = nullptr;
+  p.stamps = nullptr;
   p.dy = dy; p.x1 = x1; p.x2 = x2; p.dw = dw;
   p.B = B; p.D = D; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.N = N;
   p.nbd = (D + HB_D - 1) / HB_D; p.nbh = (H + HB_H - 1) / HB_H; p.nbw = (W + HB_W - 1) / HB_W;
@@ -1001,8 +1154,26 @@ extern "C" int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void*
     p.bricks_per_block = (p.nbricks + splits - 1) / splits;
     splits = (p.nbricks + p.bricks_per_block - 1) / p.bricks_per_block;
     CTU_REQUIRE((int64_t)tiles * splits < (1ll << 31), "conv3_halo_wgrad: too many workgroups");
-    if (ntn == 2) hipLaunchKernelGGL(conv3_halo_wgrad_dma_kernel<2>, dim3(tiles * splits), dim3(512), 0, s, p);
+    const int64_t panel = (int64_t)27 * N * (C1 + C2);
+    const bool partials = splits > 1 && ws && (int64_t)splits * panel <= ws_floats && (C1 + C2) % 4 == 0 &&
+                          !(ctu_option_route() & CTU_ROUTE_HALO_WGRAD_ATOMICS);
+    if (partials) p.part = ws;
+    if ((p.debug & 16) && partials && ntn == 2 && ws_floats >= (int64_t)splits * panel + (int64_t)tiles * splits * 8 * 8 * 2) {  // diagnostic build
+      p.stamps = ws + (int64_t)splits * panel;
+      hipLaunchKernelGGL((conv3_halo_wgrad_dma_kernel<2, false, true>), dim3(tiles * splits), dim3(512), 0, s, p);
+      return ctu_check_launch("conv3_halo_wgrad");
+    }
+    const bool burst = (ctu_option_route() & CTU_ROUTE_HALO_WGRAD_BURST) != 0;
+    if (ntn == 2 && burst) hipLaunchKernelGGL((conv3_halo_wgrad_dma_kernel<2, true>), dim3(tiles * splits), dim3(512), 0, s, p);
+    else if (ntn == 2) hipLaunchKernelGGL(conv3_halo_wgrad_dma_kernel<2>, dim3(tiles * splits), dim3(512), 0, s, p);
+    else if (burst) hipLaunchKernelGGL((conv3_halo_wgrad_dma_kernel<1, true>), dim3(tiles * splits), dim3(512), 0, s, p);
     else hipLaunchKernelGGL(conv3_halo_wgrad_dma_kernel<1>, dim3(tiles * splits), dim3(512), 0, s, p);
+    if (partials) {
+      if (panel >= 4 * 64 * 1024)
+        hipLaunchKernelGGL(halo_wgrad_reduce_kernel<4>, dim3((unsigned)((panel / 4 + 63) / 64)), dim3(256), 0, s, ws, dw, panel, splits);
+      else
+        hipLaunchKernelGGL(halo_wgrad_reduce_kernel<1>, dim3((unsigned)((panel + 63) / 64)), dim3(256), 0, s, ws, dw, panel, splits);
+    }
     return ctu_check_launch("conv3_halo_wgrad");
   }
   p.tiles_n = (N + 31) / 32;

@@ -27,6 +27,28 @@ template <> struct Mma<bf16> {
     return f;
   }
   static __device__ __forceinline__ Frag gather(const bf16* p, int stride) { return gather2(p, stride, 4); }
+  // Three k-shifted fragments from ONE fetch of twelve rows: f0 = rows 0..7, f1 = rows 1..8, f2 = rows 2..9 of this lane's column
+  // (rows 10, 11 are read and dropped).  Three transposed reads instead of six; f1 costs four v_alignbit.  Split in two so that the
+  // reads of the next k step can be in flight while the fragments of this one are cut and multiplied.
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+  static __device__ __forceinline__ void row3_fetch(const bf16* p, int stride, unsigned (&v)[5]) {
+    const int i = threadIdx.x & 15, q = i >> 2, pp = i & 3;
+    const bf16* a0 = p + q * stride + 3 * pp - 4 * q;
+    const u32x2_ r0 = __builtin_bit_cast(u32x2_, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_ptr)a0));
+    const u32x2_ r1 = __builtin_bit_cast(u32x2_, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_ptr)(a0 + 4 * stride)));
+    const u32x2_ r2 = __builtin_bit_cast(u32x2_, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_ptr)(a0 + 8 * stride)));
+    v[0] = r0[0]; v[1] = r0[1]; v[2] = r1[0]; v[3] = r1[1]; v[4] = r2[0];
+  }
+  static __device__ __forceinline__ void row3_frags(const unsigned (&v)[5], Frag& f0, Frag& f1, Frag& f2) {
+    const u32x4_ w0 = {v[0], v[1], v[2], v[3]};
+    const u32x4_ w1 = {__builtin_amdgcn_alignbit(v[1], v[0], 16), __builtin_amdgcn_alignbit(v[2], v[1], 16),
+                       __builtin_amdgcn_alignbit(v[3], v[2], 16), __builtin_amdgcn_alignbit(v[4], v[3], 16)};
+    const u32x4_ w2 = {v[1], v[2], v[3], v[4]};
+    f0 = __builtin_bit_cast(Frag, w0);
+    f1 = __builtin_bit_cast(Frag, w1);
+    f2 = __builtin_bit_cast(Frag, w2);
+  }
   // rows +0..3 and +8..11: the order in which an accumulator tile presents itself as the other MFMA operand
   static __device__ __forceinline__ Frag gather_perm(const bf16* p, int stride) { return gather2(p, stride, 8); }
   static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {

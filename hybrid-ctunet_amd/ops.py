@@ -623,8 +623,9 @@ class ConvFn(torch.autograd.Function):
                 else:
                     panel = torch.zeros((taps, N, K), dtype=torch.float32, device=x1.device)
                 if _halo_ok(k, stride, padding) and C1 % 32 == 0 and C2 % 32 == 0:
+                    wws = _wgrad_workspace(x1.device) if x1.dtype == torch.bfloat16 else None
                     call("ctu_conv3_halo_wgrad", dcode(x1.dtype), ptr(gy), ptr(x1), ptr(x2), ptr(panel), B, D, H, W, C1, C2,
-                         N, int(x1_b16), int(gy_b16), stream())
+                         N, int(x1_b16), int(gy_b16), ptr(wws), wws.numel() if wws is not None else 0, stream())
                 else:
                     gq = _geom(B, (D, H, W), dout, C1, C2, N, k, stride, padding, 0)
                     _igemm_tn(gy, N, x1, x2, panel, gq)
@@ -642,6 +643,22 @@ class ConvFn(torch.autograd.Function):
 
 
 _PANEL_SCRATCH = {}
+
+
+WGRAD_PARTIALS = True  # halo weight gradient: per-split partial panels + a reduce kernel instead of fp32 atomics
+_WGRAD_WS = {}
+
+
+def _wgrad_workspace(device):
+    """Scratch for the partial panels of ctu_conv3_halo_wgrad: 256 workgroups x 54 tiles x 1024 floats (57 MB) cover every shape
+    (splits x 27 x N x K <= that for all of them); one per (device, stream, epoch) like the other workspaces.  Contents irrelevant."""
+    if not WGRAD_PARTIALS:
+        return None
+    key = _wskey(device)
+    t = _WGRAD_WS.get(key)
+    if t is None:
+        t = _WGRAD_WS[key] = torch.empty(256 * 54 * 1024 + 27 * 64 * 1024, dtype=torch.float32, device=device)
+    return t
 
 
 def _panel_scratch(device, n):

@@ -50,7 +50,8 @@ const char* ctu_last_error(void);
  * GEMM kernels - so both implementations can be checked against the oracle in one process.  "route" = bit set of A/B
  * routing switches for measurements (1: short-K layers on the general NT kernel instead of gemm_nt_stream, 2: no 128-deep
  * stages, 4: no two-k-group trunk tiles, 8: previous channel-split rule of the small 3x3x3 convs, 16: 9-tap weight stages
- * in the halo kernels, 32: wave 0 gathers the halo alone); "nt_debug" = bits
+ * in the halo kernels, 32: wave 0 gathers the halo alone, 64: weight-gradient operand DMA in one burst, 128: weight-gradient
+ * atomics even with a workspace); "nt_debug" = bits
  * that switch a kernel's memory traffic off for timing.  Options are plain process-wide ints read per launch - no
  * launch path calls getenv. */
 int ctu_set_option(const char* name, int32_t value);
@@ -158,10 +159,13 @@ int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, const void* 
                    int32_t ldc, int32_t ldc2, double* in_acc, const void* residual, float* ws, int64_t ws_floats,
                    int32_t x1_layout, ctu_stream_t stream);
 /* Weight gradient of the same convolution with the halo staged once per brick:
- * dw[27][N][C1+C2] += sum_v dy[v][n] * x[v + tap - 1][c]  (fp32 atomics into a zeroed panel). dy: [B][D][H][W][N]. */
+ * dw[27][N][C1+C2] += sum_v dy[v][n] * x[v + tap - 1][c]  (added into the fp32 panel). dy: [B][D][H][W][N].
+ * ws (optional fp32 scratch, ws_floats entries, contents irrelevant): with room for one partial panel per brick split
+ * (256 workgroups x 54 tiles: 14.2 M floats cover every shape) the splits store plain partial panels and a second kernel
+ * adds them into dw; without it every workgroup adds its tiles with fp32 atomics. */
 int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void* x1, const void* x2, float* dw, int32_t B,
                          int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N, int32_t x1_layout,
-                         int32_t dy_layout, ctu_stream_t stream);
+                         int32_t dy_layout, float* ws, int64_t ws_floats, ctu_stream_t stream);
 /* Pack fp32 weights W(n, c, tap) = src[n*sn + c*sc + tap*st] into MFMA-fragment order
  * dst[K/32][taps][2][ceil(N/32)][64 lanes][8] (zero padded), optionally with the tap order reversed (flip = 1). */
 int ctu_pack_frag(const float* src, void* dst, ctu_dtype dst_dtype, int32_t N, int32_t K, int32_t taps, int64_t sn,

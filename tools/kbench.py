@@ -128,8 +128,9 @@ def halo(B, D, H, W, C, N, what):
     else:
         dy = torch.randn(B, D, H, W, N, device=dev, dtype=DT)
         panel = torch.zeros(27, N, C, device=dev)
+        wws = torch.empty(256 * 54 * 1024 + 27 * 64 * 1024, device=dev)
         us = timeit(lambda: call("ctu_conv3_halo_wgrad", dcode(DT), ptr(dy), ptr(x), None, ptr(panel), B, D, H, W, C, 0, N,
-                                 LAYOUT, LAYOUT, stream()))
+                                 LAYOUT, LAYOUT, ptr(wws), wws.numel(), stream()))
         report(f"conv3_halo wgrad {C}->{N} @{D}x{H}x{W} B{B}", us, flops, 2.0 * B * D * H * W * (C + N))
 
 
@@ -158,7 +159,7 @@ CASES = {
                       inorm(2, 24, 24, 48, 1024), inorm(2, 48, 48, 96, 32)],
     "wgrad_debug": lambda: [(call("ctu_set_option", b"nt_debug", d), print("nt_debug =", d),
                              halo(2, 96, 96, 96, 64, 64, "wgrad"), halo(2, 48, 48, 96, 128, 128, "wgrad"),
-                             halo(2, 24, 24, 48, 256, 256, "wgrad"), call("ctu_set_option", b"nt_debug", 0)) for d in (0, 4)],
+                             halo(2, 24, 24, 48, 256, 256, "wgrad"), call("ctu_set_option", b"nt_debug", 0)) for d in (0, 4, 1, 5)],
     "nt_small": lambda: [nt_model(55296, 256, 64, "stats", sets=8), nt_model(55296, 256, 64, "plain", sets=8),
                          nt_model(6912, 512, 128, "stats", sets=16), nt_model(6912, 512, 128, "plain", sets=16),
                          nt_model(6912, 128, 128, "plain", sets=16), nt_model(55296, 128, 64, "plain", sets=8)],
