@@ -170,6 +170,10 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (train.GraphedStep).  Off by default: on ROCm 7.2 the graph executor "
                          "serialises the captured streams (58 ms / step against 49 ms enqueued eagerly on four streams)")
+    ap.add_argument("--opt-overlap", action="store_true",
+                    help="per-bucket AdamW updates queued under the backward pass (FusedAdamW(overlap=True)) instead of one launch "
+                         "after backward().  Off by default: 47.95 - 47.98 against 48.00 - 48.20 ms per step - the update is HBM "
+                         "traffic and the step is bound by its total bytes, earlier does not make it less")
     ap.add_argument("--route", type=int, default=0,
                     help="A/B measurements: ctu_set_option(\"route\", N) bit set (include/ctunet_hip.h); 0 = the shipped routing")
     ap.add_argument("--serial", action="store_true",
@@ -210,7 +214,12 @@ def main():
     flat = H.FlatParams(order)
     dp = H.DataParallel(model, flat=flat, bucket_mb=a.bucket_mb) if world > 1 else None
     use_graph = world == 1 and a.graph and not a.serial
-    opt = H.FusedAdamW(None, lr=1e-4, weight_decay=1e-5, flat=flat, capturable=use_graph)
+    # the optimizer updates a bucket of parameters as soon as its gradients are final (behind the bucket's all-reduce for N > 1):
+    # same arithmetic as one update after backward(), queued under the rest of the backward pass (train.FusedAdamW)
+    opt_overlap = a.opt_overlap and not (a.serial or use_graph)
+    opt = H.FusedAdamW(None, lr=1e-4, weight_decay=1e-5, flat=flat, capturable=use_graph, overlap=opt_overlap and world == 1)
+    if dp is not None and opt_overlap:
+        dp.attach_optimizer(opt)
     loss_fn = H.LOSSES[a.model]
     x, y = synthetic_batch(a.batch, seed=1000 + rank)
     x, y = x.to(dev), y.to(dev)
@@ -222,6 +231,7 @@ def main():
         kernels on companion streams; the per-kernel roofline figures are taken with the overlap off, so a launch's HIP
         events bracket that kernel alone."""
         _ops.WGRAD_STREAM = not flag
+        opt.overlap_enabled = not flag
         if hasattr(model, "overlap_branches"):
             model.overlap_branches = not flag
     set_serial(a.serial)
@@ -334,7 +344,8 @@ def main():
             "config": {"workload": f"{a.model} d101 pf8, per-GPU batch {a.batch} x 1x96x96x96, fwd + DiceCE "
                                    f"(deep supervision, on-device targets) + bwd + fused AdamW"
                                    + (" + RCCL bucketed grad all-reduce" if world > 1 else ""),
-                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "launch": graph_note, **({"route": a.route} if a.route else {}),
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "launch": graph_note, "optimizer": "per-bucket updates under backward" if opt_overlap else "one update after backward",
+                       **({"route": a.route} if a.route else {}),
                        "params_M": round(n_params / 1e6, 2),
                        "final_loss": round(final_loss, 5)},
             "whole_path_tflops_per_gpu": round(whole_path, 2),

@@ -248,10 +248,18 @@ class FusedAdamW:
     SURVEY.md section 8a row D) are skipped exactly like torch skips `grad is None`."""
 
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, flat: Optional[FlatParams] = None,
-                 capturable: bool = False):
+                 capturable: bool = False, overlap: bool = False, bucket_mb: float = 64.0):
         """capturable: keep the learning rate, the step count and the bias corrections in four device words (advanced by
         a one-thread kernel in front of the update), so that step() can be captured into a HIP graph and replayed
-        (GraphedStep); change the learning rate with set_lr()."""
+        (GraphedStep); change the learning rate with set_lr().
+
+        overlap: update a bucket of parameters (~bucket_mb of the flat buffer, which lies in gradient-ready order) as soon
+        as the backward pass has finished ITS gradients, on a stream of its own - the update is pure HBM traffic and runs
+        under the matrix-bound kernels of the rest of the backward pass; step() then only updates what is left and joins.
+        Same arithmetic, element for element.  Not for a loop that inspects or rescales gradients between backward() and
+        step() (GradScaler.unscale_/step, gradient clipping): there the update has to wait for all of them - leave it
+        off.  With DataParallel (world > 1) the reducer drives it: DataParallel(..., optimizer=opt) updates a bucket
+        behind its all-reduce, on the communication stream."""
         if flat is None:
             params = list(params)
             flat = FlatParams.of(params) or FlatParams(params)   # e.g. the one DataParallel(model) built
@@ -272,6 +280,26 @@ class FusedAdamW:
         if self.capturable:
             self.hyper = torch.zeros(4, dtype=torch.float32, device=self.flat.flat.device)
             self.hyper[0] = lr
+        # ---- overlapped update (see the docstring)
+        self._done: List[Tuple[int, int]] = []   # flat ranges already updated in the step that is open
+        self._open = False                       # step_count already advanced for this iteration
+        self._ov = None
+        self.reducer_driven = False              # DataParallel(optimizer=self) calls update_range() itself
+        self.overlap_enabled = True              # (a harness may switch the per-bucket updates off for single-stream profiles)
+        if overlap and self.flat.flat.is_cuda and not self.capturable:
+            f = self.flat
+            target = int(bucket_mb * 1024 * 1024 / 4)
+            buckets, begin, members = [], 0, []
+            for i in range(len(f.params)):
+                members.append(i)
+                end = f.offsets[i + 1] if i + 1 < len(f.params) else f.total
+                if end - begin >= target or i + 1 == len(f.params):
+                    buckets.append((begin, end, members))
+                    begin, members = end, []
+            self._ov = {"buckets": buckets, "of": {i: b for b, (_, _, mem) in enumerate(buckets) for i in mem},
+                        "pending": [len(mem) for _, _, mem in buckets], "seen": [False] * len(f.params),
+                        "stream": torch.cuda.Stream(), "home": torch.cuda.current_stream()}
+            f.listeners.append(self._on_ready)
 
     def set_lr(self, lr: float):
         self.lr = self.param_groups[0]["lr"] = float(lr)
@@ -379,22 +407,71 @@ class FusedAdamW:
         self._static_skip = self.flat.untouched_ranges()
         return self._static_skip
 
-    def step(self):
-        if self.flat.flat.is_cuda:
-            ops.join_side_streams()   # weight gradients written from the ViT branch's stream
-        self.step_count += 1
-        skip = self._static_skip if self._static_skip is not None else self.flat.untouched_ranges()
+    def _on_ready(self, i):
+        """FlatParams listener (overlap=True, no reducer): the gradient of parameter i is final for this backward."""
+        ov = self._ov
+        if ov is None or self.reducer_driven or not self.overlap_enabled or ov["seen"][i]:
+            return
+        ov["seen"][i] = True
+        b = ov["of"][i]
+        ov["pending"][b] -= 1
+        if ov["pending"][b] > 0:
+            return
+        begin, end, _ = ov["buckets"][b]
+        # The update stream has to see: the kernel that wrote the last gradient (queued on the stream this callback runs
+        # under - a weight-gradient companion stream, usually), every other side stream (earlier members of the bucket), and
+        # the compute streams themselves - the data-gradient GEMM of a layer reads W (its bf16 mirror, which the update
+        # rewrites) and is queued before the layer reports its weight gradient.
+        st = ov["stream"]
+        st.wait_stream(torch.cuda.current_stream())
+        st.wait_stream(ov["home"])
+        for s2 in ops.side_streams(self.flat.flat.device):
+            st.wait_stream(s2)
+        with torch.cuda.stream(st):
+            self.update_range(begin, end)
+
+    def update_range(self, begin: int, end: int, skip: Sequence[Tuple[int, int]] = ()):
+        """AdamW on flat[begin:end) on torch's current stream; the first call of an iteration opens the step (advances
+        the step count every range of this iteration shares).  step() updates whatever no call has covered."""
+        if not self._open:
+            self.step_count += 1
+            self._open = True
         if len(skip) > 16:
             raise RuntimeError(f"{len(skip)} disjoint gradient-less parameter ranges; the fused AdamW handles up to 16")
         arr = (C.c_int64 * (2 * max(1, len(skip))))()
         for k, (a, b) in enumerate(skip):
-            arr[2 * k], arr[2 * k + 1] = a, b
+            arr[2 * k], arr[2 * k + 1] = a - begin, b - begin
         f = self.flat
         lr = self.param_groups[0]["lr"]
+        off = lambda t, es: (t.data_ptr() + es * begin) if t is not None else None
+        call("ctu_adamw", off(f.flat, 4), off(f.grad, 4), off(self.m, 4), off(self.v, 4), off(self.mirror, 2), end - begin, lr,
+             self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, arr, len(skip), ptr(self.hyper), stream())
+        self._done.append((begin, end))
+
+    def step(self):
+        if self.flat.flat.is_cuda:
+            ops.join_side_streams()   # weight gradients written from the ViT branch's stream
+        f = self.flat
+        skip = self._static_skip if self._static_skip is not None else f.untouched_ranges()
         if self.hyper is not None:
+            if not self._open:
+                self.step_count += 1
+                self._open = True
             call("ctu_adamw_tick", ptr(self.hyper), self.betas[0], self.betas[1], stream())
-        call("ctu_adamw", ptr(f.flat), ptr(f.grad), ptr(self.m), ptr(self.v), ptr(self.mirror), f.total, lr, self.betas[0],
-             self.betas[1], self.eps, self.weight_decay, self.step_count, arr, len(skip), ptr(self.hyper), stream())
+        # what the overlapped updates (update_range) have not covered yet: everything, without them
+        pos = 0
+        for a, b in sorted(self._done) + [(f.total, f.total)]:
+            if a > pos:
+                self.update_range(pos, a, [(max(x, pos), min(y, a)) for x, y in skip if x < a and y > pos])
+            pos = max(pos, b)
+        if self._ov is not None:
+            ov = self._ov
+            ov["home"] = torch.cuda.current_stream()
+            ov["home"].wait_stream(ov["stream"])
+            ov["pending"] = [len(mem) for _, _, mem in ov["buckets"]]
+            ov["seen"] = [False] * len(f.params)
+        self._done = []
+        self._open = False
         ops.bump_weights_epoch()
         if self.mirror is not None and self._mirror_stamp != (ops.mirror_generation(), tuple(p._version for p in f.params)):
             self.sync_mirror()  # someone else wrote parameters since the last sync (grad-less ones would stay stale)
@@ -461,7 +538,10 @@ class DataParallel(nn.Module):
 
     def __init__(self, module: nn.Module, flat: Optional[FlatParams] = None, bucket_mb: float = 32.0,
                  process_group=None, ready_order: Optional[Sequence[nn.Parameter]] = None, broadcast: bool = True,
-                 payload: str = "fp32", comm=None):
+                 payload: str = "fp32", comm=None, optimizer: Optional["FusedAdamW"] = None):
+        """optimizer: a FusedAdamW over the same FlatParams; every bucket is then UPDATED right behind its all-reduce, on the
+        communication stream, while the backward pass goes on (FusedAdamW(overlap=...) explains when that is allowed);
+        optimizer.step() afterwards only covers buckets flushed by finish()."""
         super().__init__()
         if payload not in ("fp32", "bf16"):
             raise ValueError("payload must be 'fp32' or 'bf16'")
@@ -497,6 +577,11 @@ class DataParallel(nn.Module):
         self._is_cuda = f.flat.is_cuda
         self._side = torch.cuda.Stream() if self._is_cuda else None
         self._seen = [False] * len(f.params)
+        self._opt = None
+        self._flushing = False
+        if optimizer is not None:
+            self.attach_optimizer(optimizer)
+        self._home = torch.cuda.current_stream() if self._is_cuda else None
         f.listeners.append(self._on_ready)  # fires for autograd-accumulated and for directly accumulated gradients
         if broadcast and self.world > 1:
             dist.broadcast(f.flat, src=0, group=self.pg)  # DDP ctor semantics: rank 0's parameters win
@@ -505,6 +590,15 @@ class DataParallel(nn.Module):
 
     def forward(self, *a, **kw):
         return self.module(*a, **kw)
+
+    def attach_optimizer(self, optimizer: "FusedAdamW"):
+        """Update every bucket right behind its all-reduce (see the constructor); a no-op for one rank or on the CPU, where
+        the optimizer's own overlap (FusedAdamW(overlap=True)) or its plain step() applies."""
+        if optimizer.flat is not self.flat:
+            raise ValueError("optimizer and DataParallel must share one FlatParams")
+        if self.world > 1 and self._is_cuda and not optimizer.capturable:
+            self._opt = optimizer
+            optimizer.reducer_driven = True
 
     def _on_ready(self, i):
         # One report per parameter and backward: autograd's AccumulateGrad node runs once however often the parameter is
@@ -531,8 +625,12 @@ class DataParallel(nn.Module):
             self._side.wait_event(ev)
             for st in ops.side_streams(sl.device):   # members of this bucket may come from the other branch's stream
                 self._side.wait_stream(st)
+            if self._opt is not None and not self._flushing:
+                self._side.wait_stream(self._home)   # data-gradient GEMMs of these layers read the weights the update rewrites
             with torch.cuda.stream(self._side):
                 self._reduce_cuda(sl)
+                if self._opt is not None and not self._flushing:  # (a flushed bucket holds gradient-less parameters: step() skips them)
+                    self._opt.update_range(begin, end)
         else:
             sl.mul_(1.0 / self.world)   # gloo (CPU tests) has no AVG
             self._works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
@@ -556,9 +654,13 @@ class DataParallel(nn.Module):
         """Call after backward, before the optimizer step."""
         if self._is_cuda:
             ops.join_side_streams()
+        self._flushing = True
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)  # buckets containing parameters that never produced a gradient
+        self._flushing = False
+        if self._is_cuda:
+            self._home = torch.cuda.current_stream()
         for w in self._works:
             w.wait()
         self._works = []

@@ -426,6 +426,71 @@ def test_training_trajectory_follows_the_oracle(H, kind, depth):
         assert ref[2] < ref[0] and got[2] < got[0]      # and it trains (TUNet at lr 1e-3 first bounces up)
 
 
+def test_overlapped_optimizer_update_equals_one_update(H):
+    """FusedAdamW(overlap=True) updates a bucket of the flat buffer as soon as the backward pass reports its last gradient (on its
+    own stream) and step() covers the rest, skipping gradient-less parameters.  Driven here with fixed gradients and explicit
+    ready reports (out of order, one parameter never reported): parameters and both moments must be bit-equal to the optimizer
+    that updates everything in step(), step after step - one shared step count per iteration, no range updated twice or missed."""
+    def make():
+        torch.manual_seed(0)
+        return [torch.nn.Parameter(torch.randn(n, device="cuda")) for n in (1000, 64 * 300, 77, 4096 * 9, 130, 5000, 12345)]
+    a, b = make(), make()
+    fa, fb = H.FlatParams(a), H.FlatParams(b)
+    oa = H.FusedAdamW(None, lr=1e-2, weight_decay=1e-2, flat=fa, overlap=True, bucket_mb=0.05)   # ~13 K floats per bucket
+    ob = H.FusedAdamW(None, lr=1e-2, weight_decay=1e-2, flat=fb)
+    assert len(oa._ov["buckets"]) >= 3
+    init2 = a[2].detach().clone()
+    for it in range(3):
+        oa.zero_grad()
+        ob.zero_grad()
+        g = torch.randn(fa.total, device="cuda", generator=torch.Generator(device="cuda").manual_seed(10 + it))
+        fa.grad.copy_(g)
+        fb.grad.copy_(g)
+        for i in (6, 0, 3, 1, 5, 4):   # parameter 2 never receives a gradient
+            fa._ready(i)
+            fb._ready(i)
+        assert oa._done, "no bucket was updated before step()"
+        oa.step()
+        ob.step()
+    torch.cuda.synchronize()
+    assert oa.step_count == ob.step_count == 3
+    assert torch.equal(fa.flat, fb.flat) and torch.equal(oa.m, ob.m) and torch.equal(oa.v, ob.v)
+    assert torch.equal(oa.mirror, ob.mirror)
+    assert torch.equal(a[2].detach(), init2)
+
+
+def test_overlapped_optimizer_in_a_training_step(H):
+    """The same through a real step (CUNet-50, bf16): per-bucket updates queued under the backward pass against one update after
+    it, from the same state.  The first loss is bit-equal (nothing was updated yet); later ones agree to the run-to-run noise of
+    the step itself (atomics of co-running kernels), and the overlapped run must have updated buckets during backward."""
+    from oracle.ctunet_oracle import synthetic_batch
+    x, y = synthetic_batch(1, seed=1000)
+    x, y = x.cuda(), y.cuda()
+    losses, early = [], 0
+    for overlap in (False, True):
+        torch.manual_seed(0)
+        m = H.build_model("cunet", model_depth=50).cuda()
+        flat = H.FlatParams(H.gradient_ready_order(m))
+        opt = H.FusedAdamW(None, lr=1e-3, weight_decay=1e-5, flat=flat, overlap=overlap, bucket_mb=16.0)
+        ls = []
+        for _ in range(3):
+            opt.zero_grad()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = H.LOSSES["cunet"](m(x), y)
+            loss.backward()
+            if overlap:
+                early += len(opt._done)
+            opt.step()
+            ls.append(loss.item())
+        losses.append(ls)
+        flat.release()
+    print(f"\nlosses: one update {losses[0]}  per-bucket {losses[1]}")
+    assert early >= 3
+    assert abs(losses[0][0] - losses[1][0]) <= 1e-3 * abs(losses[0][0])
+    for u, v in zip(losses[0][1:], losses[1][1:]):
+        assert abs(u - v) <= 2e-2 * abs(u), losses
+
+
 def test_reference_amp_call_sequence_fp16_autocast_gradscaler(H):
     """The reference trainer's step with its DEFAULT flags (amp=True): `param.grad = None` -> autocast() [float16] ->
     logits = model(data) -> five-head loss -> scaler.scale(loss).backward() -> scaler.step(optimizer) -> scaler.update()
