@@ -44,7 +44,7 @@ for (B, D, H, W, C, N) in [(2, 96, 96, 96, 64, 64), (2, 48, 48, 96, 128, 128), (
     splits = min((256 + tiles - 1) // tiles, nbricks)
     bpb = (nbricks + splits - 1) // splits
     splits = (nbricks + bpb - 1) // bpb
-    for dbg in (16, 16 | 4, 16 | 1):
+    for dbg in (16, 16 | 4):
         call("ctu_set_option", b"nt_debug", dbg)
         for _ in range(int(os.environ.get("STAMPS_LAUNCHES", "3"))):  # (hundreds: the clock the governor settles on under this load)
             call("ctu_conv3_halo_wgrad", dcode(x.dtype), ptr(dy), ptr(x), None, ptr(panel), B, D, H, W, C, 0, N, 0, 0, ptr(ws), ws.numel(),
@@ -60,13 +60,13 @@ for (B, D, H, W, C, N) in [(2, 96, 96, 96, 64, 64), (2, 48, 48, 96, 128, 128), (
         dur = raw[:, 0, 6] * 0.01
         end = start + dur
         q = lambda t, f: t.sort().values[int(f * (len(t) - 1))].item()
-        print(f"    workgroups: start spread {q(start, 0.5):.1f} / {q(start, 0.9):.1f} / {start.max().item():.1f} us (median / p90 / max), "
-              f"duration {q(dur, 0.1):.1f} / {q(dur, 0.5):.1f} / {q(dur, 0.9):.1f} / {dur.max().item():.1f} us (p10 / median / p90 / max), "
-              f"last end {end.max().item():.1f} us")
         tag = {16: "full", 20: "no operand DMA", 17: "no epilogue"}[dbg]
         if dbg & 1:
             continue  # (the no-epilogue build returns before the stamps are written)
         print(f"{C}->{N} @{D}x{H}x{W} [{tag:14s}] ({bpb} bricks per workgroup; shader clock while the kernel ran: {ghz:.2f} GHz)")
+        print(f"    workgroups: start spread {q(start, 0.5):.1f} / {q(start, 0.9):.1f} / {start.max().item():.1f} us (median / p90 / max), "
+              f"duration {q(dur, 0.1):.1f} / {q(dur, 0.5):.1f} / {q(dur, 0.9):.1f} / {dur.max().item():.1f} us (p10 / median / p90 / max), "
+              f"last end {end.max().item():.1f} us")
         for wv in range(8):
             m = med[wv]
             print(f"    wave {wv}: first operands {m[0]:6.0f}  own DMA {m[1]:6.0f}  barriers {m[2]:6.0f}  k loops {m[3]:6.0f}  epilogue {m[4]:6.0f}")
