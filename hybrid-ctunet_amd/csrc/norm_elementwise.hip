@@ -144,10 +144,14 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
                                                             const T* __restrict__ y, const float* __restrict__ stats,
                                                             double* __restrict__ sums, const int64_t S, const int C,
                                                             const int act, const int64_t rows_per_block,
-                                                            const uint8_t* __restrict__ mask) {
-  __shared__ double red[256 * 16];
+                                                            const uint8_t* __restrict__ mask, const int fold) {
+  // LDS: [256][16] doubles (32 KiB) in general; [4 waves][C / 8][16] when C / 8 is a power of two <= 64 (the lanes of a wave
+  // that share a channel group are folded by shuffles first): 4 KiB at 64 channels, 8 at 128 - small enough to sit beside a
+  // pair of halo-convolution workgroups (150 of the CU's 160 KiB), which the 32-KiB form can not
+  extern __shared__ double red[];
   const int ncg = C >> 3;
   const int tid = threadIdx.x;
+  const bool folded = fold != 0;
   const int cg = tid % ncg, rl = tid / ncg;
   const int rlanes = 256 / ncg;
   const int b = blockIdx.y;
@@ -189,6 +193,30 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
         s2[e] += (double)g[e] * (double)xh[e];
       }
     }
+  }
+  if (folded) {
+    for (int d = ncg; d < 64; d <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s1[e] += __shfl_xor(s1[e], d, 64);
+        s2[e] += __shfl_xor(s2[e], d, 64);
+      }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane < ncg) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { red[(wave * ncg + lane) * 16 + e] = s1[e]; red[(wave * ncg + lane) * 16 + 8 + e] = s2[e]; }
+    }
+    __syncthreads();
+    for (int o = tid; o < C * 2; o += 256) {
+      const int c = o >> 1, which = o & 1;
+      const int g = c >> 3, e = c & 7;
+      double acc = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) acc += red[(w * ncg + g) * 16 + which * 8 + e];
+      atomicAdd(&sums[((size_t)b * C + c) * 2 + which], acc);
+    }
+    return;
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s1[e]; red[tid * 16 + 8 + e] = s2[e]; }
@@ -350,11 +378,14 @@ extern "C" int ctu_in_bwd_reduce(ctu_dtype dtype, const void* dy, const void* x,
   const int64_t rows = in_rows_per_block(S, B, C);
   dim3 grid((unsigned)((S + rows - 1) / rows), B);
   hipStream_t s = (hipStream_t)stream;
+  const int ncg = C / 8;
+  const int fold = ncg <= 64 && (ncg & (ncg - 1)) == 0 && !(ctu_option_route() & CTU_ROUTE_IN_REDUCE_LDS32);
+  const size_t lds = fold ? (size_t)4 * ncg * 16 * sizeof(double) : (size_t)256 * 16 * sizeof(double);
   CTU_DISPATCH(dtype,
-               hipLaunchKernelGGL(in_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x,
-                                  (const float*)y, stats, sums, S, C, act, rows, sign_mask),
-               hipLaunchKernelGGL(in_bwd_reduce_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, (const bf16*)x,
-                                  (const bf16*)y, stats, sums, S, C, act, rows, sign_mask));
+               hipLaunchKernelGGL(in_bwd_reduce_kernel<float>, grid, dim3(256), lds, s, (const float*)dy, (const float*)x,
+                                  (const float*)y, stats, sums, S, C, act, rows, sign_mask, fold),
+               hipLaunchKernelGGL(in_bwd_reduce_kernel<bf16>, grid, dim3(256), lds, s, (const bf16*)dy, (const bf16*)x,
+                                  (const bf16*)y, stats, sums, S, C, act, rows, sign_mask, fold));
   return ctu_check_launch("in_bwd_reduce");
 }
 
