@@ -212,7 +212,9 @@ def main():
     n_params = sum(p.numel() for p in model.parameters())
     order = H.gradient_ready_order(model)
     flat = H.FlatParams(order)
-    dp = H.DataParallel(model, flat=flat, bucket_mb=a.bucket_mb) if world > 1 else None
+    # static_unused: the parameters without a gradient in the first (warm-up) step never get one (seven ResBlock.conv3 that the
+    # models build and never call); their buckets then go out during backward instead of behind it (train.DataParallel)
+    dp = H.DataParallel(model, flat=flat, bucket_mb=a.bucket_mb, static_unused=a.warmup > 0) if world > 1 else None
     use_graph = world == 1 and a.graph and not a.serial
     # the optimizer updates a bucket of parameters as soon as its gradients are final (behind the bucket's all-reduce for N > 1):
     # same arithmetic as one update after backward(), queued under the rest of the backward pass (train.FusedAdamW)

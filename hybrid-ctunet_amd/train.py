@@ -538,11 +538,18 @@ class DataParallel(nn.Module):
 
     def __init__(self, module: nn.Module, flat: Optional[FlatParams] = None, bucket_mb: float = 32.0,
                  process_group=None, ready_order: Optional[Sequence[nn.Parameter]] = None, broadcast: bool = True,
-                 payload: str = "fp32", comm=None, optimizer: Optional["FusedAdamW"] = None):
+                 payload: str = "fp32", comm=None, optimizer: Optional["FusedAdamW"] = None, static_unused: bool = False):
         """optimizer: a FusedAdamW over the same FlatParams; every bucket is then UPDATED right behind its all-reduce, on the
         communication stream, while the backward pass goes on (FusedAdamW(overlap=...) explains when that is allowed);
-        optimizer.step() afterwards only covers buckets flushed by finish()."""
+        optimizer.step() afterwards only covers buckets flushed by finish().
+        static_unused: the parameters that produced no gradient in the FIRST backward never will (DDP's static_graph; true of
+        the reference models: the seven ResBlock.conv3 of CTUNet with in == out channels are built and never called).  From
+        the second step on a bucket then goes out as soon as its USED members are ready instead of waiting for finish() -
+        in CTUNet the three buckets that finish first (110 MB) hold such parameters and would otherwise be reduced behind
+        the backward pass, exposed.  A gradient reported for one of them later raises."""
         super().__init__()
+        self._static_unused = bool(static_unused)
+        self._unused = None   # set of parameter indices, learnt in the first finish()
         if payload not in ("fp32", "bf16"):
             raise ValueError("payload must be 'fp32' or 'bf16'")
         self.module = module
@@ -605,6 +612,9 @@ class DataParallel(nn.Module):
         # used (the engine sums the contributions first), and the direct gradient sinks report only after the LAST of the
         # uses counted in forward (ops.sink_expect / sink_done).  A duplicate report is ignored all the same.
         if self._seen[i]:
+            if self._unused is not None and i in self._unused:
+                raise RuntimeError(f"DataParallel(static_unused=True): parameter {i} produced no gradient in the first step "
+                                   "but does now; its bucket may already have been reduced")
             return
         self._seen[i] = True
         b = self._bucket_of[i]
@@ -666,9 +676,12 @@ class DataParallel(nn.Module):
         self._works = []
         if self._is_cuda and self.world > 1:
             torch.cuda.current_stream().wait_stream(self._side)
-        self._pending = [len(mem) for _, _, mem in self.buckets]
+        if self._static_unused and self._unused is None:
+            self._unused = {i for i, s in enumerate(self._seen) if not s}
+        unused = self._unused or ()
+        self._pending = [sum(1 for i in mem if i not in unused) for _, _, mem in self.buckets]
         self._launched = [False] * len(self.buckets)
-        self._seen = [False] * len(self.flat.params)
+        self._seen = [i in unused for i in range(len(self.flat.params))]
         ops.reset_grad_sink_counts()
 
 

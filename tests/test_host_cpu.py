@@ -153,15 +153,20 @@ def _dp_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(123 + rank)  # different init per rank: the wrapper must broadcast rank 0's parameters
     m = _Toy()
-    dp = train.DataParallel(m, bucket_mb=0.0005)  # tiny buckets -> several of them
+    dp = train.DataParallel(m, bucket_mb=0.0005, static_unused=True)  # tiny buckets -> several of them
     assert hasattr(dp, "module") and len(dp.buckets) >= 2
     g = torch.Generator().manual_seed(7)
     x = torch.randn(8, 12, generator=g)
     xs = x[rank * 4:(rank + 1) * 4]
-    for step in range(2):
+    early = []
+    for step in range(3):
         dp.flat.zero_grad()
         dp(xs).pow(2).mean().backward()
+        early.append(sum(dp._launched))   # buckets that went out during backward, before finish() flushes the rest
         dp.finish()
+    # static_unused: from the second step on the bucket(s) holding the never-used Linear no longer wait for finish()
+    assert early[0] < len(dp.buckets) and early[1] == early[2] == len(dp.buckets), early
+    assert dp._unused == {i for i, p in enumerate(dp.flat.params) if any(p is q for q in m.unused.parameters())}
     torch.save({"grad": dp.flat.grad.clone(), "flat": dp.flat.flat.clone()}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
