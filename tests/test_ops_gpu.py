@@ -683,6 +683,34 @@ def test_conv3d_halo_spread_gather_bit_equal(ops, case, route):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
+@pytest.mark.parametrize("case", [(2, 8, 16, 16, 64, 64), (1, 5, 9, 11, 128, 96), (2, 4, 8, 8, 32, 32), (1, 9, 17, 10, 64, 256)])
+def test_conv3d_halo_weight_gradient_partial_panels(ops, case):
+    """The weight-gradient halo kernel stores one partial panel per brick split and a second kernel adds them in a fixed order
+    (ops.WGRAD_PARTIALS, workspace argument of ctu_conv3_halo_wgrad); ctu_set_option("route", 128) keeps the fp32 atomics.  Two
+    runs with partial panels must be bit-equal (no atomics left in the path), and both routes agree to fp32 rounding of the
+    split sums.  Ragged volumes, one- and two-n-tile workgroups, N not a multiple of 64."""
+    from hybrid_ctunet_amd import _lib
+    B, D, H, W, C, N = case
+    x0 = rnd((B, D, H, W, C), 51).to(torch.bfloat16).cuda()
+    w = torch.nn.Parameter(rnd((N, C, 3, 3, 3), 52, 1 / math.sqrt(27 * C)).float().cuda())
+    gout = rnd((B, D, H, W, N), 53).to(torch.bfloat16).cuda()
+
+    def run(route):
+        _lib.call("ctu_set_option", b"route", route)
+        try:
+            w.grad = None
+            y = ops.conv3d(x0, w, 1, 1)
+            y.backward(gout)
+            torch.cuda.synchronize()
+            return w.grad.clone()
+        finally:
+            _lib.call("ctu_set_option", b"route", 0)
+    a, b, c = run(0), run(0), run(128)
+    assert torch.equal(a, b)
+    scale = c.abs().max().item()
+    assert (a - c).abs().max().item() <= 2e-5 * scale + 1e-30
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_instance_norm_sign_mask_equals_reading_y(ops, dtype):
     """With a residual, the backward kernels take the LeakyReLU mask from the byte-per-8-channels sign mask the forward wrote
