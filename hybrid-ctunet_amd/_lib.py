@@ -45,7 +45,7 @@ class AttnGeom(C.Structure):
 _SIGS = {
     "ctu_igemm_nt": [_i32, _vp, _vp, _vp, _vp, C.POINTER(Geom), C.POINTER(Epilogue), _vp],
     "ctu_igemm_tn": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, C.POINTER(Geom), _vp, _i64, _vp],
-    "ctu_conv3_halo": [_i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 10 + [_vp, _vp, _vp, _i64, _i32, _vp],
+    "ctu_conv3_halo": [_i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 10 + [_vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "ctu_in_finalize": [_i32, _i64, _i32, _vp, _vp, _vp],
     "ctu_conv3_halo_wgrad": [_i32, _vp, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _i64, _vp],
     "ctu_pack_frag": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp],
@@ -130,7 +130,7 @@ def lib():
         L.ctu_allreduce_scratch_bytes.argtypes = [_i32, _i64]
         L.ctu_allreduce_scratch_bytes.restype = _i64
         L.ctu_last_error.restype = C.c_char_p
-        if L.ctu_abi_version() != 4:
+        if L.ctu_abi_version() != 5:
             raise RuntimeError("libctunet_hip.so ABI version mismatch")
         _lib = L
     return _lib

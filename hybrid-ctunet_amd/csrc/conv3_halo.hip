@@ -32,7 +32,8 @@ struct HaloArgs {
   int B, D, H, W, C1, C2, N, n_split, ldc, ldc2;
   int nbd, nbh, nbw, ntn;  // brick grid, 32-wide n tiles in the whole panel
   double* in_acc;          // optional [B][N][2]: += (sum y, sum y^2) per batch item and channel (InstanceNorm statistics)
-  const void* residual;    // optional [rows][ldc] (same dtype): added to the result (bf16 DMA kernel, n_split == 0)
+  const void* residual;    // optional [rows][ldc] (same dtype): added to the part of the result that goes to `out` (bf16 DMA kernel)
+  const void* residual2;   // optional [rows][ldc2]: added to the part that goes to `out2` (n_split > 0)
   float* part;             // split over input channels (small volumes): fp32 partial outputs [split][rows][ntn * 32], else NULL
   int hc_per_split;        // 16-channel half chunks per split (blockIdx.z)
   // source layout of x1 (bf16 DMA kernel): element (voxel m, channel c) sits at m * vs1 + (c >> 4) * bs1 + (c & 15).
@@ -515,8 +516,15 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
           load8(&stage[row * STAGE_LD + cv * 8], xv);
           const size_t m = (((size_t)b * p.D + gd) * p.H + gh) * p.W + gw;
           if (p.part) store8(p.part + ((size_t)blockIdx.z * p.B * p.D * p.H * p.W + m) * (p.ntn * 32) + n, xv);
-          else if (p.n_split > 0 && n >= p.n_split) store8(out2 + m * p.ldc2 + (n - p.n_split), xv);
-          else {
+          else if (p.n_split > 0 && n >= p.n_split) {
+            if (p.residual2) {
+              float rr[8];
+              load8(reinterpret_cast<const bf16*>(p.residual2) + m * p.ldc2 + (n - p.n_split), rr);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) xv[e] += rr[e];
+            }
+            store8(out2 + m * p.ldc2 + (n - p.n_split), xv);
+          } else {
             if (p.residual) {
               float rr[8];
               load8(reinterpret_cast<const bf16*>(p.residual) + m * p.ldc + n, rr);
@@ -600,7 +608,7 @@ template <> struct HaloDma<bf16> {
     const int blocks = bricks * (ntn / NT);
     int ksplit = 1;
     const int64_t rows = (int64_t)p.B * p.D * p.H * p.W;
-    if (ws && !p.residual && blocks < 256 && rows <= 16384 && HCT >= 4 && p.n_split == 0 && p.N % 8 == 0 && p.N <= 2048 && p.ldc % 8 == 0) {
+    if (ws && !p.residual && !p.residual2 && blocks < 256 && rows <= 16384 && HCT >= 4 && p.n_split == 0 && p.N % 8 == 0 && p.N <= 2048 && p.ldc % 8 == 0) {
       // fill the 512 resident slots (2 workgroups per CU) ONCE: rounding up (540 workgroups for 512 -> 512 @ 12 x 12 x 24)
       // costs a second round for a handful of stragglers; down to one half chunk (9 stages) per workgroup if need be
       // (256 -> 256 @ 6 x 6 x 12: 72.6 -> 28.1 us)
@@ -664,8 +672,8 @@ static int launch_halo(const HaloArgs& p, float* ws, int64_t ws_floats, hipStrea
 
 extern "C" int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, const void* wfrag, void* out, void* out2,
                               int32_t B, int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N,
-                              int32_t n_split, int32_t ldc, int32_t ldc2, double* in_acc, const void* residual, float* ws,
-                              int64_t ws_floats, int32_t x1_layout, ctu_stream_t stream) {
+                              int32_t n_split, int32_t ldc, int32_t ldc2, double* in_acc, const void* residual,
+                              const void* residual2, float* ws, int64_t ws_floats, int32_t x1_layout, ctu_stream_t stream) {
   CTU_REQUIRE(x1 && wfrag && out, "conv3_halo: null pointer");
   CTU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3_halo: bad dims");
   CTU_REQUIRE(C1 > 0 && C1 % 32 == 0 && C2 >= 0 && C2 % 32 == 0 && (C2 == 0 || x2), "conv3_halo: C1, C2 must be multiples of 32");
@@ -676,9 +684,11 @@ extern "C" int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, c
   p.B = B; p.D = D; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.N = N; p.n_split = n_split; p.ldc = ldc; p.ldc2 = ldc2;
   p.in_acc = in_acc;
   p.residual = residual;
-  CTU_REQUIRE(!residual || (dtype == CTU_BF16 && n_split == 0 && !in_acc &&
-                            (int64_t)B * D * H * W * (C1 > C2 ? C1 : C2) < (1ll << 31)),
-              "conv3_halo: a residual input needs the bf16 LDS-DMA kernel without split / statistics");
+  p.residual2 = residual2;
+  CTU_REQUIRE((!residual && !residual2) || (dtype == CTU_BF16 && !in_acc &&
+                                            (int64_t)B * D * H * W * (C1 > C2 ? C1 : C2) < (1ll << 31)),
+              "conv3_halo: a residual input needs the bf16 LDS-DMA kernel without statistics");
+  CTU_REQUIRE(!residual2 || (n_split > 0 && out2), "conv3_halo: residual2 belongs to the out2 part of a split output");
   p.part = nullptr;
   p.hc_per_split = (C1 + C2) / 16;
   CTU_REQUIRE(x1_layout == CTU_LAYOUT_NDHWC || (x1_layout == CTU_LAYOUT_B16 && dtype == CTU_BF16 &&

@@ -54,13 +54,21 @@ class ResBlock(nn.Module):
         # identity shortcut: its gradient is folded into conv1's data-gradient epilogue (ops.GradStash) instead of an
         # autograd accumulation pass over three full-size tensors
         stash = [] if (not self.downsample and inp.requires_grad and torch.is_grad_enabled()) else None
-        y1 = self.conv1(inp, inp2, grad_stash=stash)
+        # conv shortcut (in != out channels, stride 1): conv3 reads the same input (pair) as conv1; its data gradients are parked
+        # (GradStash on conv3's inputs) and added inside conv1's data-gradient kernel - no autograd accumulation pass over
+        # three full-size tensors per input (680 MB each at vit_decoder0)
+        stash1 = stash2 = None
+        if self.downsample and ops.STASH_SHORTCUT_CONV and torch.is_grad_enabled() and ops._halo_ok(self.conv1.kernel_size, self.conv1.stride, self.conv1.padding):
+            stash1 = [] if inp.requires_grad else None
+            stash2 = [] if (inp2 is not None and inp2.requires_grad) else None
+        y1 = self.conv1(inp, inp2, grad_stash=stash if stash is not None else stash1, grad_stash2=stash2)
         c2 = self.conv2
         # norm1's output feeds conv2 only: written 16-channel-blocked when conv2 runs on the halo kernel (ops.wants_b16)
         out = ops.instance_norm(y1, None, True, out_b16=ops.wants_b16(c2.conv.weight, y1, c2.stride, c2.padding))
         out = self.conv2(out)
         if self.downsample:
-            residual = ops.instance_norm(self.conv3(inp, inp2), None, False)
+            residual = ops.instance_norm(self.conv3(ops.GradStash.apply(inp, stash1) if stash1 is not None else inp,
+                                                    ops.GradStash.apply(inp2, stash2) if stash2 is not None else inp2), None, False)
         else:
             assert inp2 is None
             residual = ops.GradStash.apply(inp, stash) if stash is not None else inp

@@ -71,7 +71,7 @@ class ConvLayer(nn.Module):
         else:
             self.conv = nn.Conv3d(in_channels, out_channels, k, stride=s, padding=p, bias=bias)
 
-    def forward(self, x, x2=None, grad_stash=None):
+    def forward(self, x, x2=None, grad_stash=None, grad_stash2=None):
         w = self.conv.weight
         if self.is_transposed:
             assert x2 is None
@@ -82,7 +82,7 @@ class ConvLayer(nn.Module):
         if x2 is None and self.kernel_size == (1, 1, 1) and self.stride == (1, 1, 1):
             # every 1x1x1 ConvLayer of these networks feeds an InstanceNorm
             return ops.linear(x, w, in_stats=True, grad_stash=grad_stash)
-        return ops.conv3d(x, w, self.stride, self.padding, x2, grad_stash=grad_stash)
+        return ops.conv3d(x, w, self.stride, self.padding, x2, grad_stash=grad_stash, grad_stash2=grad_stash2)
 
 
 def get_conv_layer(spatial_dims: int, in_channels: int, out_channels: int, kernel_size=3, stride=1, act=None,

@@ -493,6 +493,9 @@ class LinearFn(torch.autograd.Function):
         return gx, gw, gb, gres, None, None, None
 
 
+STASH_SHORTCUT_CONV = True  # ResBlock with a conv shortcut: conv3's data gradients added inside conv1's data-gradient kernel
+
+
 class GradStash(torch.autograd.Function):
     """Identity whose backward parks the incoming gradient in `slot` (a list) instead of returning it.  Used on the
     residual branch of a bottleneck: the branch's gradient w.r.t. the block input is then added inside the data-gradient
@@ -528,9 +531,10 @@ class ConvFn(torch.autograd.Function):
     Reference: get_conv_layer, networks/resnet.py:17-50 (3x3x3 s1/s2, 1x1x1 s2)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, stride, padding, grad_stash=None, x1_b16=False, link=None):
+    def forward(ctx, x1, x2, weight, stride, padding, grad_stash=None, x1_b16=False, link=None, grad_stash2=None):
         _check_act(x1)
         ctx.grad_stash = grad_stash
+        ctx.grad_stash2 = grad_stash2 if x2 is not None else None
         ctx.x1_b16 = bool(x1_b16)
         ctx.link = link
         B, D, H, W, C1 = x1.shape
@@ -550,7 +554,7 @@ class ConvFn(torch.autograd.Function):
                 acc = _in_acc_take(x1.device, B * N * 2)
             ws = _tn_workspace(x1.device)
             call("ctu_conv3_halo", dcode(x1.dtype), ptr(x1), ptr(x2), ptr(wfr), ptr(out), None, B, D, H, W, C1, C2, N, 0,
-                 N, 0, ptr(acc[1]) if acc is not None else None, None, ptr(ws), ws.numel(), int(ctx.x1_b16), stream())
+                 N, 0, ptr(acc[1]) if acc is not None else None, None, None, ptr(ws), ws.numel(), int(ctx.x1_b16), stream())
             ctx.in_acc = acc
             # the InstanceNorm that follows may hand this conv's data- and weight-gradient kernels their dY in the blocked
             # layout (they are its only readers)
@@ -597,13 +601,20 @@ class ConvFn(torch.autograd.Function):
                 # dX = conv(dY, W flipped, in/out channels swapped): W'(n'=cin, c'=cout, t') = W[cout][cin][26 - t']
                 wfr = _packed_frag(weight, "conv_hd", x1.dtype, K, N, taps, taps, K * taps, 1, 1)
                 ws = _tn_workspace(x1.device)
-                extra = None
-                if ctx.grad_stash and x2 is None and x1.dtype == torch.bfloat16 and B * D * H * W * max(N, K) < (1 << 31):
-                    extra = ctx.grad_stash.pop()  # gradient of x1 through another branch: added in the epilogue
-                    if extra.shape != x1.shape or extra.dtype != x1.dtype or not extra.is_contiguous():
-                        extra = extra.to(x1.dtype).contiguous().view_as(x1)
+                extra = extra2 = None
+                if x1.dtype == torch.bfloat16 and B * D * H * W * max(N, K) < (1 << 31):
+                    # gradients of x1 / x2 through another branch (GradStash): added in the epilogue
+                    if ctx.grad_stash:
+                        extra = ctx.grad_stash.pop()
+                        if extra.shape != x1.shape or extra.dtype != x1.dtype or not extra.is_contiguous():
+                            extra = extra.to(x1.dtype).contiguous().view_as(x1)
+                    if ctx.grad_stash2 and x2 is not None:
+                        extra2 = ctx.grad_stash2.pop()
+                        if extra2.shape != x2.shape or extra2.dtype != x2.dtype or not extra2.is_contiguous():
+                            extra2 = extra2.to(x2.dtype).contiguous().view_as(x2)
                 call("ctu_conv3_halo", dcode(x1.dtype), ptr(gy), None, ptr(wfr), ptr(g1), ptr(g2), B, D, H, W, N, 0, K,
-                     C1 if x2 is not None else 0, C1, C2, None, ptr(extra), ptr(ws), ws.numel(), int(gy_b16), stream())
+                     C1 if x2 is not None else 0, C1, C2, None, ptr(extra), ptr(extra2), ptr(ws), ws.numel(), int(gy_b16),
+                     stream())
             else:
                 # dX[v][c] = sum_t sum_n dY[(v + p - t)/s][n] W[n][c][t]  ->  panel [t][c][n]
                 wd = _packed(weight, "conv_d", x1.dtype,
@@ -639,7 +650,9 @@ class ConvFn(torch.autograd.Function):
                     permute3(panel, gw, (N, K, taps), (K, 1, N * K), (K * taps, taps, 1))
         if ctx.grad_stash:  # not consumed by a fused epilogue (generic path): add it here
             g1 = g1 + ctx.grad_stash.pop().to(g1.dtype)
-        return g1, g2, gw, None, None, None, None, None
+        if ctx.grad_stash2:
+            g2 = g2 + ctx.grad_stash2.pop().to(g2.dtype)
+        return g1, g2, gw, None, None, None, None, None, None
 
 
 _PANEL_SCRATCH = {}
@@ -818,13 +831,14 @@ def _pack(weight, n, src_strides, dtype):
     return out
 
 
-def conv3d(x1, weight, stride=1, padding=0, x2=None, grad_stash=None):
+def conv3d(x1, weight, stride=1, padding=0, x2=None, grad_stash=None, grad_stash2=None):
     global _last_in_acc
     _last_in_acc = None
     global _last_b16_grad_ok
     _last_b16_grad_ok = False
     link = _B16Link()
-    out = ConvFn.apply(x1, x2, weight, _t3(stride), _t3(padding), grad_stash, bool(getattr(x1, "_ctu_b16", False)), link)
+    out = ConvFn.apply(x1, x2, weight, _t3(stride), _t3(padding), grad_stash, bool(getattr(x1, "_ctu_b16", False)), link,
+                       grad_stash2)
     if _last_in_acc is not None:
         out._ctu_in_acc = _last_in_acc  # instance_norm(out, ...) picks the statistics up instead of re-reading `out`
         _last_in_acc = None

@@ -148,16 +148,18 @@ int ctu_conv_cin1_wgrad(ctu_dtype dtype, const void* x, const void* dy, float* d
  * in_acc (optional, fp64 [B][N][2], bf16 / n_split == 0 only): += (sum y, sum y^2) of the fp32 accumulators per batch
  * item and output channel - the InstanceNorm statistics of the layer that follows (resnet.py:97-99), so that no
  * separate pass re-reads the output; turn them into (mean, rstd) with ctu_in_finalize.
- * residual (optional, [rows][ldc] bf16, n_split == 0, no in_acc): added to the result - used by the data gradient to fold
- * in a gradient that reached the same tensor through another branch (identity shortcut of a ResBlock).
+ * residual (optional, [rows][ldc] bf16, no in_acc): added to the part of the result that goes to `out` - used by the data
+ * gradient to fold in a gradient that reached the same tensor through another branch (identity shortcut of a ResBlock);
+ * residual2 (optional, [rows][ldc2], n_split > 0): the same for the part that goes to `out2` (a block whose shortcut
+ * convolution reads the same channel-concatenated pair of tensors as its first convolution).
  * ws (optional fp32 scratch, ws_floats entries, contents irrelevant): volumes of a few bricks (the 12x12x24 and
  * 6x6x12 stages) split their input channels over workgroups, keep fp32 partial outputs there and sum them in a
  * second pass (bf16, n_split == 0).
  * x1_layout: ctu_layout of x1 (x2 is always channels-last). */
 int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, const void* wfrag, void* out, void* out2,
                    int32_t B, int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N, int32_t n_split,
-                   int32_t ldc, int32_t ldc2, double* in_acc, const void* residual, float* ws, int64_t ws_floats,
-                   int32_t x1_layout, ctu_stream_t stream);
+                   int32_t ldc, int32_t ldc2, double* in_acc, const void* residual, const void* residual2, float* ws,
+                   int64_t ws_floats, int32_t x1_layout, ctu_stream_t stream);
 /* Weight gradient of the same convolution with the halo staged once per brick:
  * dw[27][N][C1+C2] += sum_v dy[v][n] * x[v + tap - 1][c]  (added into the fp32 panel). dy: [B][D][H][W][N].
  * ws (optional fp32 scratch, ws_floats entries, contents irrelevant): with room for one partial panel per brick split

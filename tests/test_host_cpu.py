@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in ctunet_hip.h but not exported"
     assert sorted(_lib.EXPORTED) == declared, "python binding table and header disagree"
     lib.ctu_abi_version.restype = ctypes.c_int
-    assert lib.ctu_abi_version() == 4
+    assert lib.ctu_abi_version() == 5
 
 
 def test_ctypes_struct_layouts_match_header():

@@ -711,6 +711,44 @@ def test_conv3d_halo_weight_gradient_partial_panels(ops, case):
     assert (a - c).abs().max().item() <= 2e-5 * scale + 1e-30
 
 
+@pytest.mark.parametrize("two", [False, True])
+def test_resblock_conv_shortcut_gradients_folded_into_conv1(ops, two):
+    """ResBlock with a conv shortcut (in != out channels): conv3 reads the same input (or channel-concatenated pair of inputs) as
+    conv1.  Its data gradients are parked (GradStash) and added in the epilogue of conv1's data-gradient halo kernel - for a
+    pair of inputs through `residual` AND `residual2` of ctu_conv3_halo - instead of by autograd's accumulation passes.  Input
+    gradients must agree with the accumulated ones to one bf16 rounding (the folded form rounds once), weight gradients
+    exactly (they do not depend on where the sum is taken)."""
+    from hybrid_ctunet_amd.networks.hybrid_CTUNet import ResBlock
+    torch.manual_seed(0)
+    C1, C2, N = 64, (64 if two else 0), 32
+    blk = ResBlock(3, C1 + C2, N, 3, 1, "instance").cuda()
+    a0 = rnd((1, 6, 9, 10, C1), 61).to(torch.bfloat16).cuda()
+    b0 = rnd((1, 6, 9, 10, C2), 62).to(torch.bfloat16).cuda() if two else None
+    gy = rnd((1, 6, 9, 10, N), 63).to(torch.bfloat16).cuda()
+
+    def run(flag):
+        ops.STASH_SHORTCUT_CONV = flag
+        try:
+            a = a0.clone().requires_grad_(True)
+            b = b0.clone().requires_grad_(True) if two else None
+            for p in blk.parameters():
+                p.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = blk(a, b)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            return [a.grad.clone()] + ([b.grad.clone()] if two else []), [blk.conv1.conv.weight.grad.clone(), blk.conv3.conv.weight.grad.clone()]
+        finally:
+            ops.STASH_SHORTCUT_CONV = True
+    (gi_f, gw_f), (gi_a, gw_a) = run(True), run(False)
+    for u, v in zip(gi_f, gi_a):
+        scale = v.float().abs().max().item()
+        assert (u.float() - v.float()).abs().max().item() <= 2 ** -7 * scale
+        assert (u.float() - v.float()).abs().mean().item() <= 2 ** -9 * v.float().abs().mean().item()
+    for u, v in zip(gw_f, gw_a):
+        assert torch.allclose(u, v, rtol=1e-5, atol=1e-6 * v.abs().max().item())
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_instance_norm_sign_mask_equals_reading_y(ops, dtype):
     """With a residual, the backward kernels take the LeakyReLU mask from the byte-per-8-channels sign mask the forward wrote

@@ -17,7 +17,7 @@ for (B, D, H, W, C, N) in ([] if os.environ.get('STAMPS_WGRAD_ONLY') else [(2, 9
     for dbg in (16, 16 | 8, 16 | 4, 16 | 12):
         call("ctu_set_option", b"nt_debug", dbg)
         for _ in range(3):
-            call("ctu_conv3_halo", dcode(x.dtype), ptr(x), None, ptr(wfr), ptr(out), None, B, D, H, W, C, 0, N, 0, N, 0, None, None,
+            call("ctu_conv3_halo", dcode(x.dtype), ptr(x), None, ptr(wfr), ptr(out), None, B, D, H, W, C, 0, N, 0, N, 0, None, None, None,
                  ptr(ws), ws.numel(), 0, stream())
         torch.cuda.synchronize()
         call("ctu_set_option", b"nt_debug", 0)
