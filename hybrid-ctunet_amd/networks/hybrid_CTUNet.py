@@ -96,8 +96,8 @@ class UpCatConvBlock(nn.Module):
                                           stride=upsample_kernel_size, conv_only=True, is_transposed=True)
         self.conv_block = ResBlock(spatial_dims, out_channels + out_channels, out_channels, kernel_size, 1, norm_name)
 
-    def forward(self, inp, skip):
-        return self.conv_block(self.transp_conv(inp), skip)
+    def forward(self, inp, skip, grad_stash=None):
+        return self.conv_block(self.transp_conv(inp, grad_stash=grad_stash), skip)
 
 
 class UpConvBlock(nn.Module):
@@ -110,8 +110,8 @@ class UpConvBlock(nn.Module):
                                           stride=upsample_kernel_size, conv_only=True, is_transposed=True)
         self.conv_block = ResBlock(spatial_dims, out_channels, out_channels, kernel_size, 1, norm_name)
 
-    def forward(self, inp):
-        return self.conv_block(self.transp_conv(inp))
+    def forward(self, inp, grad_stash=None):
+        return self.conv_block(self.transp_conv(inp, grad_stash=grad_stash))
 
 
 class CatConvBlock(nn.Module):
@@ -171,9 +171,9 @@ class Up_2Fusion_Block(nn.Module):
         """First half of forward (hybrid_CTUNet.py:333-334): depends on the two encoders only, not on the decoder below."""
         return self.up_addconv_block1(self.pixelweight_attention1(skip_conv, skip_vit))
 
-    def main_path(self, inp, skip):
+    def main_path(self, inp, skip, grad_stash=None):
         """Second half (hybrid_CTUNet.py:336-340)."""
-        out = self.transp_conv(inp)
+        out = self.transp_conv(inp, grad_stash=grad_stash)
         return self.up_addconv_block2(self.pixelweight_attention2(out, skip))
 
     def forward(self, inp, skip_conv=None, skip_vit=None):
@@ -505,6 +505,10 @@ class CTUNet(_VitBranch):
         # backward pass.  ResNet first: in backward the ViT branch finishes early and the long convnet backward, which
         # releases its gradients layer by layer down to the small stem, hides the communication (train.DataParallel).
         join_side = False
+        # res_dec2 / res_dec1 feed the next decoder's transposed conv AND a deep-supervision head: the head's gradient is parked
+        # (GradStash) and added in the epilogue of the transposed conv's data-gradient GEMM
+        grad = torch.is_grad_enabled()
+        stash2, stash1 = ([] if grad else None), ([] if grad else None)
         if self.overlap_branches:
             # ... and they run CONCURRENTLY, on two HIP streams: the ViT trunk (864 tokens) and the small-volume stages of both
             # branches are latency-bound launches that leave most of the 256 CUs idle; side by side they fill each other's
@@ -539,9 +543,10 @@ class CTUNet(_VitBranch):
             x.record_stream(side)
             res_dec = res_enc4
             decs = []
-            for d, t, ev in zip((self.res_decoder3, self.res_decoder2, self.res_decoder1), skips, skip_ready):
+            for d, t, ev, st in zip((self.res_decoder3, self.res_decoder2, self.res_decoder1), skips, skip_ready,
+                                    (None, None, stash2)):   # res_decoder1's transposed conv reads res_dec2
                 main.wait_event(ev)
-                res_dec = d.main_path(res_dec, t)
+                res_dec = d.main_path(res_dec, t, grad_stash=st)
                 decs.append(res_dec)
             res_dec3, res_dec2, res_dec1 = decs
             join_side = True
@@ -550,11 +555,12 @@ class CTUNet(_VitBranch):
             vit_enc, vit_logits, vit_96x96 = self._vit_forward(x)
             res_dec3 = self.res_decoder3(res_enc4, res_enc3, vit_enc[1])
             res_dec2 = self.res_decoder2(res_dec3, res_enc2, vit_enc[2])
-            res_dec1 = self.res_decoder1(res_dec2, res_enc1, vit_enc[3])
-        res_out = self.res_decoder0(res_dec1)
+            res_dec1 = self.res_decoder1.main_path(res_dec2, self.res_decoder1.skip_path(res_enc1, vit_enc[3]), grad_stash=stash2)
+        park = lambda t, st: ops.GradStash.apply(t, st) if (st is not None and t.requires_grad) else t
+        res_out = self.res_decoder0(res_dec1, grad_stash=stash1 if res_dec1.requires_grad else None)
         res_logits = self.res_out(res_out)
-        res_logits_48x48 = self.res_out_48x48(res_dec1)
-        res_logits_24x24 = self.res_out_24x24(res_dec2)
+        res_logits_48x48 = self.res_out_48x48(park(res_dec1, stash1))
+        res_logits_24x24 = self.res_out_24x24(park(res_dec2, stash2))
         if join_side:
             torch.cuda.current_stream().wait_stream(ops.side_stream(x.device))   # the ViT-branch logits
         return self._outputs(((res_logits, res_logits_48x48, res_logits_24x24), (vit_logits, vit_96x96)))
@@ -581,10 +587,13 @@ class CUNet(_Base):
         x = self._input(x_in)
         res_enc1, res_enc2, res_enc3, res_enc4 = self.convnet(x)
         res_dec3 = self.res_decoder3(res_enc4, res_enc3)
+        grad = torch.is_grad_enabled()
+        stash2, stash1 = ([] if grad else None), ([] if grad else None)   # see CTUNet.forward
+        park = lambda t, st: ops.GradStash.apply(t, st) if (st is not None and t.requires_grad) else t
         res_dec2 = self.res_decoder2(res_dec3, res_enc2)
-        res_dec1 = self.res_decoder1(res_dec2, res_enc1)
-        res_out = self.res_decoder0(res_dec1)
-        return self._outputs((self.res_out(res_out), self.res_out_48x48(res_dec1), self.res_out_24x24(res_dec2)))
+        res_dec1 = self.res_decoder1(res_dec2, res_enc1, grad_stash=stash2 if res_dec2.requires_grad else None)
+        res_out = self.res_decoder0(res_dec1, grad_stash=stash1 if res_dec1.requires_grad else None)
+        return self._outputs((self.res_out(res_out), self.res_out_48x48(park(res_dec1, stash1)), self.res_out_24x24(park(res_dec2, stash2))))
 
 
 class TUNet(_VitBranch):

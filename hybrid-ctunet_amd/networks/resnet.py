@@ -75,7 +75,7 @@ class ConvLayer(nn.Module):
         w = self.conv.weight
         if self.is_transposed:
             assert x2 is None
-            return ops.conv_transpose3d(x, w)
+            return ops.conv_transpose3d(x, w, grad_stash=grad_stash)
         if self.in_channels == 1:
             assert x2 is None
             return ops.conv3d_cin1(x, w, self.stride, self.padding)
@@ -127,7 +127,9 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        stash = [] if (self.downsample is None and x.requires_grad and torch.is_grad_enabled()) else None
+        # shortcut (identity, or conv + norm in the first block of a stage): its gradient w.r.t. x is parked (GradStash) and
+        # added inside conv1's data-gradient GEMM instead of by an autograd accumulation pass
+        stash = [] if (x.requires_grad and torch.is_grad_enabled()) else None
         y1 = self.conv1(x, grad_stash=stash)
         c2 = self.conv2
         # gn1's output feeds conv2 only: written 16-channel-blocked when conv2 runs on the halo kernel (ops.wants_b16)
@@ -135,7 +137,7 @@ class Bottleneck(nn.Module):
         out = ops.instance_norm(self.conv2(out), None, True)
         out = self.conv3(out)
         if self.downsample is not None:
-            residual = self.downsample(x)
+            residual = self.downsample(ops.GradStash.apply(x, stash) if stash is not None else x)
         else:
             # identity shortcut: its gradient is folded into conv1's data-gradient GEMM (ops.GradStash)
             residual = ops.GradStash.apply(x, stash) if stash is not None else x

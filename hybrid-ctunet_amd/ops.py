@@ -877,8 +877,9 @@ class ConvTransposeFn(torch.autograd.Function):
     weight: [Cin, Cout, kd, kh, kw]."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, grad_stash=None):
         _check_act(x)
+        ctx.grad_stash = grad_stash   # gradient of x through another consumer (GradStash): added in the data-gradient epilogue
         B, D, H, W, Cin = x.shape
         Cout = weight.shape[1]
         k = tuple(weight.shape[2:])
@@ -907,18 +908,21 @@ class ConvTransposeFn(torch.autograd.Function):
             wd = _packed(weight, "convt_d", x.dtype,
                          lambda: _pack(weight, (taps, Cin, Cout), (1, Cout * taps, taps), x.dtype))
             gx = torch.empty_like(x)
-            _igemm_nt(gy, None, wd, gx, _geom(B, dbig, (D, H, W), Cout, 0, Cin, k, k, (0, 0, 0), 0), _epi(Cin))
+            extra = ctx.grad_stash.pop() if ctx.grad_stash else None
+            if extra is not None and (extra.shape != x.shape or extra.dtype != x.dtype or not extra.is_contiguous()):
+                extra = extra.to(x.dtype).contiguous().view_as(x)
+            _igemm_nt(gy, None, wd, gx, _geom(B, dbig, (D, H, W), Cout, 0, Cin, k, k, (0, 0, 0), 0), _epi(Cin, residual=extra))
         if ctx.needs_input_grad[1]:
             # dW[ci][co][t] = sum_v x[v][ci] dY[v*k + t][co]: P = x (N := Cin), Q = dY gathered (C := Cout)
             panel = torch.zeros((taps, Cin, Cout), dtype=torch.float32, device=x.device)
             _igemm_tn(x, Cin, gy, None, panel, _geom(B, dbig, (D, H, W), Cout, 0, Cin, k, k, (0, 0, 0), 0))
             gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
             permute3(panel, gw, (Cin, Cout, taps), (Cout, 1, Cin * Cout), (Cout * taps, taps, 1))
-        return gx, gw
+        return gx, gw, None
 
 
-def conv_transpose3d(x, weight):
-    return ConvTransposeFn.apply(x, weight)
+def conv_transpose3d(x, weight, grad_stash=None):
+    return ConvTransposeFn.apply(x, weight, grad_stash)
 
 
 class ConvCin1Fn(torch.autograd.Function):
