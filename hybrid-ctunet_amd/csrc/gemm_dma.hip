@@ -344,7 +344,8 @@ __global__ __launch_bounds__(256 * KG, (KG == 2 || R * (BM + BN) * BK * 2 > 76 *
             if (m < p.M && n < p.N) {
               bf16* dst;
               const size_t off = epilogue_offset(p.ep, out, m, n, dst);
-              v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.ep.residual) + off);
+              if (dst == out)   // (split output: the residual belongs to the `out` part)
+                v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.ep.residual) + off);
             }
             resv[i * NR + t] = v;
           }

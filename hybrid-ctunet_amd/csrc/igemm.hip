@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtArgs p) {
         } else {
           off = (size_t)m * ep.ldc + n;
         }
-        if (res) {
+        if (res && dst == out) {  // (split output: the residual belongs to the `out` part)
           float rr[8];
           load8(res + off, rr);
 #pragma unroll

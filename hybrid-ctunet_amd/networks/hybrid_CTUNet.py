@@ -50,7 +50,9 @@ class ResBlock(nn.Module):
         if not np.all(np.atleast_1d(stride) == 1):
             self.downsample = True
 
-    def forward(self, inp, inp2=None):
+    def forward(self, inp, inp2=None, grad_stash=None):
+        # grad_stash: a list another consumer of `inp` parks its gradient in (ops.GradStash, created AFTER this block); it is
+        # added in the data-gradient epilogue of the first convolution of this block that autograd replays.
         # identity shortcut: its gradient is folded into conv1's data-gradient epilogue (ops.GradStash) instead of an
         # autograd accumulation pass over three full-size tensors
         stash = [] if (not self.downsample and inp.requires_grad and torch.is_grad_enabled()) else None
@@ -61,14 +63,19 @@ class ResBlock(nn.Module):
         if self.downsample and ops.STASH_SHORTCUT_CONV and torch.is_grad_enabled() and ops._halo_ok(self.conv1.kernel_size, self.conv1.stride, self.conv1.padding):
             stash1 = [] if inp.requires_grad else None
             stash2 = [] if (inp2 is not None and inp2.requires_grad) else None
-        y1 = self.conv1(inp, inp2, grad_stash=stash if stash is not None else stash1, grad_stash2=stash2)
+        if grad_stash is not None and stash is not None:
+            raise NotImplementedError("an outside gradient stash and an identity shortcut share conv1's one residual input")
+        own = stash if stash is not None else stash1
+        y1 = self.conv1(inp, inp2, grad_stash=own if own is not None else grad_stash, grad_stash2=stash2)
         c2 = self.conv2
         # norm1's output feeds conv2 only: written 16-channel-blocked when conv2 runs on the halo kernel (ops.wants_b16)
         out = ops.instance_norm(y1, None, True, out_b16=ops.wants_b16(c2.conv.weight, y1, c2.stride, c2.padding))
         out = self.conv2(out)
         if self.downsample:
+            # (conv3 is replayed before conv1: it takes the outside stash, its own input gradients go on to conv1)
             residual = ops.instance_norm(self.conv3(ops.GradStash.apply(inp, stash1) if stash1 is not None else inp,
-                                                    ops.GradStash.apply(inp2, stash2) if stash2 is not None else inp2), None, False)
+                                                    ops.GradStash.apply(inp2, stash2) if stash2 is not None else inp2,
+                                                    grad_stash=grad_stash if stash1 is not None else None), None, False)
         else:
             assert inp2 is None
             residual = ops.GradStash.apply(inp, stash) if stash is not None else inp
@@ -121,8 +128,8 @@ class CatConvBlock(nn.Module):
         super().__init__()
         self.conv_block = ResBlock(spatial_dims, in_channels + in_channels, in_channels, kernel_size, 1, norm_name)
 
-    def forward(self, x, skip):
-        return self.conv_block(x, skip)
+    def forward(self, x, skip, grad_stash=None):
+        return self.conv_block(x, skip, grad_stash=grad_stash)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -464,8 +471,12 @@ class _VitBranch(_Base):
 
     def _vit_heads(self, x, vit_enc):
         """vit_encoder0 / vit_decoder0 and the two ViT-branch heads (hybrid_CTUNet.py:822,831-835)."""
-        vit_out = self.vit_decoder0(vit_enc[4], self.vit_encoder0(x))
-        return self.vit_out(vit_out), self.decoder_linear_96x96(vit_enc[4])
+        # vit_enc[4] is read by vit_decoder0 and by the 96 x 96 head: the head's gradient is parked and added inside the
+        # data-gradient GEMM of vit_decoder0's shortcut conv (ResBlock.forward)
+        top = vit_enc[4]
+        st = [] if (torch.is_grad_enabled() and top.requires_grad and ops.STASH_SHORTCUT_CONV) else None
+        vit_out = self.vit_decoder0(top, self.vit_encoder0(x), grad_stash=st)
+        return self.vit_out(vit_out), self.decoder_linear_96x96(ops.GradStash.apply(top, st) if st is not None else top)
 
     def _vit_forward(self, x):
         vit_enc = self._vit_pyramid(x)

@@ -622,7 +622,14 @@ class ConvFn(torch.autograd.Function):
                 gd = _geom(B, dout, (D, H, W), N, 0, K, k, stride, padding, 1)
                 Mi = B * D * H * W
                 sk = _conv_splitk(Mi, K, N, taps) if x2 is None else 1
-                _igemm_nt(gy, None, wd, g1, gd, _epi(C1, out2=g2, n_split=C1 if x2 is not None else 0, ldc2=C2, splitk=sk,
+                extra = None
+                if ctx.grad_stash and sk == 1:
+                    # gradient of x1 through another consumer (GradStash): added in this GEMM's epilogue (to the x1 columns)
+                    extra = ctx.grad_stash.pop()
+                    if extra.shape != x1.shape or extra.dtype != x1.dtype or not extra.is_contiguous():
+                        extra = extra.to(x1.dtype).contiguous().view_as(x1)
+                _igemm_nt(gy, None, wd, g1, gd, _epi(C1, residual=extra, out2=g2, n_split=C1 if x2 is not None else 0, ldc2=C2,
+                                                     splitk=sk,
                                                      splitk_ws=_splitk_workspace(x1.device, Mi * K) if sk > 1 else None))
         if ctx.needs_input_grad[2]:
             gw_buf, gw_done = _direct_grad(weight) if taps > 1 else (None, None)

@@ -77,7 +77,8 @@ typedef struct ctu_geom {
 /* Epilogue of ctu_igemm_nt. */
 typedef struct ctu_epilogue {
   const float* bias;    /* [N] fp32 or NULL                                  */
-  const void* residual; /* [M][ldc] same dtype as out, added after act, or NULL */
+  const void* residual; /* [M][ldc] same dtype as out, added after act, or NULL; with a split output (n_split > 0) it is
+                         * added to the columns that go to `out` only */
   int32_t act;          /* 0 none, 1 exact-erf GELU                           */
   int32_t ldc;          /* leading dimension (elements) of out                */
   void* out2;           /* second destination for columns >= n_split, or NULL  */

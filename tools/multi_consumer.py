@@ -51,6 +51,6 @@ for (node, idx), cnt in multi.items():
 loss.backward()
 torch.cuda.synchronize()
 for numel, name, cnt, shape, par in sorted(rows, key=lambda r: -r[0])[:60]:
-    if any(q.startswith("GradStash") for q in par) and cnt == 2:
-        continue   # the second gradient is parked and added inside the first consumer's data-gradient kernel: no pass
+    if sum(1 for q in par if not q.startswith("GradStash")) <= 1:
+        continue   # the other gradients are parked and added inside the remaining consumer's data-gradient kernel: no pass
     print(f"{numel * 2 / 1e6:8.1f} MB  {name}  {shape}\n             <- {par}")
