@@ -41,6 +41,61 @@ __global__ __launch_bounds__(512) void mfma_kernel(const bf16x8* __restrict__ in
   if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// The inner loop of the halo convolution, both bf16 MFMA shapes at the same 64 x 128 output tile per wave, every operand re-read
+// from LDS (ds_read_b128, random bf16 data) each k step: 32x32x16 = 2 A + 4 B fragments and 8 MFMAs per 16 k; 16x16x32 = 4 A +
+// 8 B fragments and 32 MFMAs per 32 k - the same LDS bytes and the same pipe cycles per FLOP.  MI355X_MICROARCH.md (DVFS item 7)
+// reports that the clock the chip holds under such a load depends on the shape; this measures it here.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int SHAPE>
+__global__ __launch_bounds__(512) void lds_mfma_kernel(const bf16x8* __restrict__ in, float* __restrict__ out, int iters,
+                                                       uint64_t* __restrict__ clk) {
+  __shared__ bf16x8 lds[64 * 64];  // 64 KiB of fragments
+  for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) lds[i] = in[(i * 7 + (i >> 6)) & 255];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+  if (SHAPE == 32) {
+    f32x16 c[2][4];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) c[i][j][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {  // two k16 steps = 32 k
+        const int base = ((it * 2 + ks + wave * 5) & 7) * 6 * 64 + lane;
+        bf16x8 a[2], b[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = lds[(base + i * 64) & 4095];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = lds[(base + (2 + j) * 64) & 4095];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], c[i][j], 0, 0, 0);
+      }
+    }
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) s += c[i][j][e];
+  } else {
+    f32x4 c[4][8];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 8; ++j) for (int e = 0; e < 4; ++e) c[i][j][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+      const int base = ((it + wave * 5) & 3) * 12 * 64 + lane;
+      bf16x8 a[4], b[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = lds[(base + i * 64) & 4095];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[j] = lds[(base + (4 + j) * 64) & 4095];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], c[i][j], 0, 0, 0);
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 8; ++j) for (int e = 0; e < 4; ++e) s += c[i][j][e];
+  }
+  const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (s == 12345.678f) out[0] = s;
+  if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 __global__ __launch_bounds__(256) void read_kernel(const u32x4* __restrict__ src, uint32_t* __restrict__ sink, size_t n) {
   u32x4 acc = {0u, 0u, 0u, 0u};
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -99,6 +154,26 @@ int main() {
     const double cyc = (double)hc[0] / (16.0 * iters * (wpw / 4));
     printf("mfma_f32_32x32x16_bf16, %d waves/CU: %.1f TFLOP/s dense bf16; in-kernel clock median %.3f GHz (min %.3f max %.3f); "
            "%.2f cycles per MFMA per SIMD\n", wpw, flop / ms / 1e9, ghz[cus / 2], ghz.front(), ghz.back(), cyc);
+  }
+
+  // ---- the two bf16 MFMA shapes fed from LDS, two waves per SIMD ----
+  for (int shape : {32, 16, 32, 16}) {
+    const int iters = 20000;
+    auto launch = [&]() {
+      if (shape == 32) hipLaunchKernelGGL(lds_mfma_kernel<32>, dim3(cus), dim3(512), 0, 0, din, dout, iters, dclk);
+      else hipLaunchKernelGGL(lds_mfma_kernel<16>, dim3(cus), dim3(512), 0, 0, din, dout, iters, dclk);
+    };
+    for (int i = 0; i < 120; ++i) launch();
+    CK(hipDeviceSynchronize());
+    const double ms = time_ms([&](int) { launch(); }, 5);
+    std::vector<uint64_t> hc(2 * cus);
+    CK(hipMemcpy(hc.data(), dclk, 16 * cus, hipMemcpyDeviceToHost));
+    std::vector<double> ghz;
+    for (int b = 0; b < cus; ++b) ghz.push_back((double)hc[2 * b] / (double)hc[2 * b + 1] * 0.1);
+    std::sort(ghz.begin(), ghz.end());
+    const double flop = 2.0 * 64 * 128 * 32 * (double)iters * 8 * cus;
+    printf("LDS-fed 64x128 wave tile, %s, 8 waves/CU: %.1f TFLOP/s; in-kernel clock median %.3f GHz; %.0f cycles per 32-k step per wave pair\n",
+           shape == 32 ? "v_mfma_f32_32x32x16_bf16" : "v_mfma_f32_16x16x32_bf16", flop / ms / 1e9, ghz[cus / 2], (double)hc[0] / iters);
   }
 
   // ---- HBM ----
