@@ -463,7 +463,7 @@ class LinearFn(torch.autograd.Function):
             gx = torch.empty_like(x)
             # gradient that reached x through another branch (GradStash): added in this GEMM's epilogue instead of by
             # a separate autograd accumulation pass over three tensors
-            extra = ctx.grad_stash.pop() if ctx.grad_stash else None
+            extra = _take(ctx.grad_stash)
             if extra is not None and (extra.shape != x.shape or extra.dtype != x.dtype or not extra.is_contiguous()):
                 extra = extra.to(x.dtype).contiguous().view_as(x)
             if USE_W_KN and x.dtype == torch.bfloat16 and N % 64 == 0 and K % 8 == 0:
@@ -496,6 +496,26 @@ class LinearFn(torch.autograd.Function):
 STASH_SHORTCUT_CONV = True  # ResBlock with a conv shortcut: conv3's data gradients added inside conv1's data-gradient kernel
 
 
+_CONSUMED = object()   # left in a stash slot by its consumer: a gradient parked afterwards would be lost
+
+
+def _take(slot):
+    """The gradient parked in `slot` (None if there is none), and the slot marked as read: GradStash.backward raises if it
+    comes later - autograd replayed the two nodes in the other order and the parked gradient would silently be dropped."""
+    if slot is None:
+        return None
+    g = None
+    if slot and slot[-1] is not _CONSUMED:
+        g = slot.pop()
+    if not slot or slot[-1] is not _CONSUMED:
+        slot.append(_CONSUMED)
+    return g
+
+
+def _parked(slot) -> bool:
+    return bool(slot) and slot[-1] is not _CONSUMED
+
+
 class GradStash(torch.autograd.Function):
     """Identity whose backward parks the incoming gradient in `slot` (a list) instead of returning it.  Used on the
     residual branch of a bottleneck: the branch's gradient w.r.t. the block input is then added inside the data-gradient
@@ -509,6 +529,9 @@ class GradStash(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.slot and ctx.slot[-1] is _CONSUMED:
+            raise RuntimeError("GradStash: the consumer of this slot ran before the gradient was parked (the stash node must be "
+                               "created after the consuming layer's node, on the same stream)")
         ctx.slot.append(g)
         return None, None
 
@@ -604,12 +627,12 @@ class ConvFn(torch.autograd.Function):
                 extra = extra2 = None
                 if x1.dtype == torch.bfloat16 and B * D * H * W * max(N, K) < (1 << 31):
                     # gradients of x1 / x2 through another branch (GradStash): added in the epilogue
-                    if ctx.grad_stash:
-                        extra = ctx.grad_stash.pop()
+                    extra = _take(ctx.grad_stash)
+                    if extra is not None:
                         if extra.shape != x1.shape or extra.dtype != x1.dtype or not extra.is_contiguous():
                             extra = extra.to(x1.dtype).contiguous().view_as(x1)
-                    if ctx.grad_stash2 and x2 is not None:
-                        extra2 = ctx.grad_stash2.pop()
+                    extra2 = _take(ctx.grad_stash2) if x2 is not None else None
+                    if extra2 is not None:
                         if extra2.shape != x2.shape or extra2.dtype != x2.dtype or not extra2.is_contiguous():
                             extra2 = extra2.to(x2.dtype).contiguous().view_as(x2)
                 call("ctu_conv3_halo", dcode(x1.dtype), ptr(gy), None, ptr(wfr), ptr(g1), ptr(g2), B, D, H, W, N, 0, K,
@@ -623,9 +646,10 @@ class ConvFn(torch.autograd.Function):
                 Mi = B * D * H * W
                 sk = _conv_splitk(Mi, K, N, taps) if x2 is None else 1
                 extra = None
-                if ctx.grad_stash and sk == 1:
+                if sk == 1:
                     # gradient of x1 through another consumer (GradStash): added in this GEMM's epilogue (to the x1 columns)
-                    extra = ctx.grad_stash.pop()
+                    extra = _take(ctx.grad_stash)
+                if extra is not None:
                     if extra.shape != x1.shape or extra.dtype != x1.dtype or not extra.is_contiguous():
                         extra = extra.to(x1.dtype).contiguous().view_as(x1)
                 _igemm_nt(gy, None, wd, g1, gd, _epi(C1, residual=extra, out2=g2, n_split=C1 if x2 is not None else 0, ldc2=C2,
@@ -655,10 +679,10 @@ class ConvFn(torch.autograd.Function):
                 else:
                     gw = torch.empty(weight.shape, dtype=torch.float32, device=x1.device)
                     permute3(panel, gw, (N, K, taps), (K, 1, N * K), (K * taps, taps, 1))
-        if ctx.grad_stash:  # not consumed by a fused epilogue (generic path): add it here
-            g1 = g1 + ctx.grad_stash.pop().to(g1.dtype)
-        if ctx.grad_stash2:
-            g2 = g2 + ctx.grad_stash2.pop().to(g2.dtype)
+        if _parked(ctx.grad_stash):  # not consumed by a fused epilogue (generic path): add it here
+            g1 = g1 + _take(ctx.grad_stash).to(g1.dtype)
+        if _parked(ctx.grad_stash2):
+            g2 = g2 + _take(ctx.grad_stash2).to(g2.dtype)
         return g1, g2, gw, None, None, None, None, None, None
 
 
@@ -915,7 +939,7 @@ class ConvTransposeFn(torch.autograd.Function):
             wd = _packed(weight, "convt_d", x.dtype,
                          lambda: _pack(weight, (taps, Cin, Cout), (1, Cout * taps, taps), x.dtype))
             gx = torch.empty_like(x)
-            extra = ctx.grad_stash.pop() if ctx.grad_stash else None
+            extra = _take(ctx.grad_stash)
             if extra is not None and (extra.shape != x.shape or extra.dtype != x.dtype or not extra.is_contiguous()):
                 extra = extra.to(x.dtype).contiguous().view_as(x)
             _igemm_nt(gy, None, wd, gx, _geom(B, dbig, (D, H, W), Cout, 0, Cin, k, k, (0, 0, 0), 0), _epi(Cin, residual=extra))
@@ -1147,7 +1171,7 @@ class LayerNormFn(torch.autograd.Function):
             gg_done = gb_done = None
         ws = torch.empty(1024 * 2 * dim, dtype=torch.float32, device=x.device)  # CTU_LN_BWD_MAX_BLOCKS partial rows
         # gradient that reached x around the norm (residual branch, GradStash): added while dx is written
-        extra = ctx.grad_stash.pop() if ctx.grad_stash else None
+        extra = _take(ctx.grad_stash)
         if extra is not None and (extra.shape != x.shape or extra.dtype != x.dtype or not extra.is_contiguous()):
             extra = extra.to(x.dtype).contiguous().view_as(x)
         call("ctu_layernorm_bwd_add", dcode(x.dtype), ptr(gy), ptr(x), ptr(gamma), ptr(mr), ptr(extra), ptr(gx), ptr(gg_buf),
