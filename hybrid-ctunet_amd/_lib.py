@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libctunet_hip.so")
 SOURCES = ["igemm.hip", "gemm_dma.hip", "conv3_halo.hip", "norm_elementwise.hip", "attention.hip", "attention_mfma.hip",
-           "loss_optim.hip", "infer.hip", "dropout.hip", "comm.hip", "philox.h", "mma.h", "dma.h", "gemm_dma.h", "attn_common.h", "common.h"]
+           "loss_optim.hip", "infer.hip", "dropout.hip", "comm.hip", "plan.hip", "plan_dispatch.inc", "philox.h", "mma.h", "dma.h", "gemm_dma.h", "attn_common.h", "common.h"]
 
 CTU_F32, CTU_BF16 = 0, 1
 LAYOUT_NDHWC, LAYOUT_B16 = 0, 1
@@ -91,6 +91,9 @@ _SIGS = {
     "ctu_comm_init": [C.c_char_p, _i32, _i32, _vp, C.POINTER(_vp)],
     "ctu_comm_destroy": [_vp],
     "ctu_allreduce_bucket": [_vp, _vp, _i64, _i32, _vp, _i64, _vp],
+    "ctu_plan_create": [C.POINTER(C.c_uint64), _i64, C.POINTER(C.c_uint64), _i64, _i32, _i32, C.POINTER(_vp)],
+    "ctu_plan_run": [_vp, C.POINTER(C.c_uint64), _i32, C.POINTER(_vp), _i32],
+    "ctu_plan_destroy": [_vp],
 }
 EXPORTED = sorted(list(_SIGS) + ["ctu_abi_version", "ctu_last_error", "ctu_allreduce_scratch_bytes"])
 
@@ -130,7 +133,7 @@ def lib():
         L.ctu_allreduce_scratch_bytes.argtypes = [_i32, _i64]
         L.ctu_allreduce_scratch_bytes.restype = _i64
         L.ctu_last_error.restype = C.c_char_p
-        if L.ctu_abi_version() != 5:
+        if L.ctu_abi_version() != 6:
             raise RuntimeError("libctunet_hip.so ABI version mismatch")
         _lib = L
     return _lib

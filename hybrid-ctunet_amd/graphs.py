@@ -76,6 +76,29 @@ def graph_stages(model: nn.Module, x_in: torch.Tensor, stages: Iterable[str] = D
     that step, and the engine would tie them into the capture (ROCm 7.2 then crashes in hipStreamEndCapture)."""
     import gc
     gc.collect()
+    # The capture's warm-up passes run backward with uninitialised upstream gradients; whoever listens to "gradient ready"
+    # (FusedAdamW(overlap=True) would UPDATE the weights from them, DataParallel would all-reduce them and keep the buckets
+    # marked as launched) must not hear them: the owners' listeners are detached for the duration of the capture.
+    owners = {}
+    for p in model.parameters():
+        o = getattr(p, "_ctu_flat", None)
+        o = o() if o is not None else None
+        if o is not None:
+            owners[id(o)] = o
+    if flat is not None:
+        owners[id(flat)] = flat
+    saved_listeners = {k: o.listeners for k, o in owners.items()}
+    for o in owners.values():
+        o.listeners = []
+    try:
+        return _graph_stages(model, x_in, stages, autocast_dtype, flat)
+    finally:
+        for k, o in owners.items():
+            o.listeners = saved_listeners[k]
+        ops.reset_grad_sink_counts()
+
+
+def _graph_stages(model, x_in, stages, autocast_dtype, flat):
     mods = dict(model.named_modules())
     targets: Dict[str, nn.Module] = {}
     installs = {}

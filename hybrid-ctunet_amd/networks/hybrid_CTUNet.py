@@ -22,7 +22,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, ops_fused
 from .resnet import check_norm, generate_model as resnet, get_conv_layer
 from .vit import ViT, _check_dropout, feed_forward
 
@@ -311,6 +311,8 @@ class UpAttentionBlock(nn.Module):
 
     @staticmethod
     def _run_stage(blk, ind, x):
+        if ops_fused.up_stage_ok(x, blk, ind, blk.training):
+            return ops_fused.up_stage(blk, ind, x)   # the stage as one autograd node replayed from launch lists
         if ind <= 2:
             x = blk[1](x, part=1)   # block windows + residual
             x = blk[2](x)           # FF + residual

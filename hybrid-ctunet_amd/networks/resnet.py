@@ -13,7 +13,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, ops_fused
 
 
 def get_inplanes():
@@ -127,6 +127,8 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if ops_fused.bottleneck_ok(self, x):
+            return ops_fused.bottleneck(self, x)   # one autograd node, forward / backward replayed from launch lists
         # shortcut (identity, or conv + norm in the first block of a stage): its gradient w.r.t. x is parked (GradStash) and
         # added inside conv1's data-gradient GEMM instead of by an autograd accumulation pass
         stash = [] if (x.requires_grad and torch.is_grad_enabled()) else None

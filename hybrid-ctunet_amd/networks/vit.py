@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from .. import ops
+from .. import ops, ops_fused
 
 
 def pair(t):
@@ -130,6 +130,8 @@ class ViT(nn.Module):
         graphed = getattr(self, "_graphed_transformer", None)   # graphs.graph_stages: the 12 blocks as two graph launches
         if graphed is not None:
             return graphed(x)
+        if ops_fused.vit_trunk_ok(self, x):
+            return ops_fused.vit_trunk(self.transformer, x)   # the 12 blocks as one autograd node replayed from launch lists
         for blk in self.transformer:
             x = blk(x)
         return x

@@ -640,10 +640,27 @@ class DataParallel(nn.Module):
             with torch.cuda.stream(self._side):
                 self._reduce_cuda(sl)
                 if self._opt is not None and not self._flushing:  # (a flushed bucket holds gradient-less parameters: step() skips them)
-                    self._opt.update_range(begin, end)
+                    # static_unused: this bucket may hold members that never receive a gradient; torch.optim.AdamW leaves
+                    # `grad is None` parameters untouched (no weight decay, no state) and so does the fused update
+                    self._opt.update_range(begin, end, self._unused_ranges(b))
         else:
             sl.mul_(1.0 / self.world)   # gloo (CPU tests) has no AVG
             self._works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _unused_ranges(self, b) -> List[Tuple[int, int]]:
+        """Aligned flat ranges of the never-used members of bucket b (merged where adjacent)."""
+        if not self._unused:
+            return []
+        f, out = self.flat, []
+        for i in self.buckets[b][2]:
+            if i in self._unused:
+                o = f.offsets[i]
+                end = o + (f.params[i].numel() + f.ALIGN - 1) // f.ALIGN * f.ALIGN
+                if out and out[-1][1] == o:
+                    out[-1] = (out[-1][0], end)
+                else:
+                    out.append((o, end))
+        return out
 
     def _reduce_cuda(self, sl):
         """Mean of one bucket slice over the ranks, on the side stream.  payload "fp32": one RCCL all-reduce with the

@@ -373,6 +373,24 @@ int64_t ctu_allreduce_scratch_bytes(int32_t world, int64_t n);
 int ctu_allreduce_bucket(void* handle, float* buf, int64_t n, int32_t payload, void* scratch, int64_t scratch_bytes,
                          ctu_stream_t stream);
 
+/* ---- launch lists (host path) -------------------------------------------------------------------------------------------
+ * The reference dispatches one ATen op per Python call (e.g. the nine leaf ops of Bottleneck.forward, networks/resnet.py:
+ * 106-126, or the ~20 of its backward); the per-op crossing of the language boundary, not the device, then sets the pace of
+ * the small-volume stages.  A plan is a recorded list of calls of THIS library's entry points - the argument blocks of one
+ * module's forward or backward - created once and replayed by one call per (module, pass):
+ *   words   : commands [opcode, stream index, n, n argument words]...; argument words follow the entry point's prototype
+ *             (one 8-byte word per scalar / pointer, floats as their bit pattern, ctu_geom / ctu_epilogue / ctu_attn_geom
+ *             inline); opcodes are the indices of csrc/plan_dispatch.inc (generated from this header), 1000 = record event
+ *             w[0] on the stream, 1001 = make the stream wait for event w[0].
+ *   patches : triples (word position, slot, byte offset): before a replay word[position] = slots[slot] + offset - the
+ *             device pointers (and run-time integers) of this call's tensors.
+ * ctu_plan_run calls the entry points in order on streams[stream index]; it stops at the first failing command and
+ * reports its index in ctu_last_error().  A plan is not re-entrant (one replay at a time); different plans are independent. */
+int ctu_plan_create(const uint64_t* words, int64_t nwords, const uint64_t* patches, int64_t npatches, int32_t nevents,
+                    int32_t nslots, void** handle);
+int ctu_plan_run(void* handle, const uint64_t* slots, int32_t nslots, void* const* streams, int32_t nstreams);
+int ctu_plan_destroy(void* handle);
+
 /* fp32 <-> dtype casts and fills */
 int ctu_cast(const void* src, ctu_dtype src_dtype, void* dst, ctu_dtype dst_dtype, int64_t n, ctu_stream_t stream);
 

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, kind):
+def _worker(rank, world, port, out_dir, kind, reducer_opt=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -32,9 +32,12 @@ def _worker(rank, world, port, out_dir, kind):
     torch.manual_seed(100 + rank)                      # different initial weights: the constructor's broadcast must win
     model = H.build_model(kind, model_depth=50).to(dev)
     flat = H.FlatParams(H.gradient_ready_order(model))
-    dp = H.DataParallel(model, flat=flat, bucket_mb=8.0)
+    dp = H.DataParallel(model, flat=flat, bucket_mb=8.0, static_unused=reducer_opt)
     assert len(dp.buckets) >= 4
     opt = H.FusedAdamW(None, lr=1e-3, weight_decay=1e-5, flat=flat)
+    if reducer_opt:
+        dp.attach_optimizer(opt)   # every bucket updated right behind its all-reduce, on the communication stream
+        assert dp._opt is opt
     x, y = synthetic_batch(1, seed=1000 + rank)        # different data per rank
     x, y = x.to(dev), y.to(dev)
     grads = []
@@ -50,7 +53,10 @@ def _worker(rank, world, port, out_dir, kind):
         grads.append(flat.grad.detach().cpu().clone())
         opt.step()
     torch.cuda.synchronize()
-    torch.save({"flat": flat.flat.detach().cpu(), "grads": grads, "loss": float(loss)}, os.path.join(out_dir, f"r{rank}.pt"))
+    tag = "o" if reducer_opt else "r"
+    torch.save({"flat": flat.flat.detach().cpu(), "grads": grads, "loss": float(loss), "m": opt.m.detach().cpu(),
+                "v": opt.v.detach().cpu(), "skip": opt._static_skip,
+                "unused": sorted(dp._unused) if dp._unused else []}, os.path.join(out_dir, f"{tag}{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,6 +72,25 @@ def test_two_ranks_on_one_gpu_stay_identical(tmp_path, kind):
         assert torch.isfinite(g0).all() and g0.abs().max() > 0
     assert torch.equal(r0["flat"], r1["flat"])          # three identical AdamW updates on the broadcast parameters
     assert r0["loss"] != r1["loss"]                     # ... although the ranks saw different data
+
+
+def test_reducer_driven_optimizer_leaves_gradient_less_parameters_alone(tmp_path):
+    """DataParallel(static_unused=True, optimizer=opt): from the second step on a bucket holding never-used parameters goes out
+    during backward and is UPDATED behind its all-reduce.  torch.optim.AdamW (the reference's optimizer) does not touch a
+    parameter whose grad is None - no weight decay, no state - and neither may the per-bucket update: weights and moments
+    must be bit-equal to the plain finish() + step() sequence."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "ctunet", False), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "ctunet", True), nprocs=2, join=True)
+    plain = torch.load(os.path.join(tmp_path, "r0.pt"))
+    over = torch.load(os.path.join(tmp_path, "o0.pt"))
+    over1 = torch.load(os.path.join(tmp_path, "o1.pt"))
+    assert over["unused"], "CTUNet builds ResBlock.conv3 tensors it never calls"
+    assert torch.equal(over["flat"], over1["flat"])
+    for k in ("flat", "m", "v"):
+        assert torch.equal(plain[k], over[k]), k
+    for a, b in over["skip"]:                            # the gradient-less ranges: no decay, no moments
+        assert (over["m"][a:b] == 0).all() and (over["v"][a:b] == 0).all()
 
 
 def test_ctunet_gradients_become_ready_in_bucket_order():

@@ -1,0 +1,148 @@
+"""Fused module-level path (ops_fused.py: one autograd node per block, forward / backward replayed from C-side launch lists,
+csrc/plan.hip) against the per-op path (ops.py) it replaces: same kernels, same arguments, same order - so the results must
+agree to the last bits the fp64 statistics atomics leave open.  Every case runs the fused path twice (the first call
+records, the second replays into freshly allocated tensors)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(block, x, gy, fused, flat=None):
+    from hybrid_ctunet_amd import ops_fused as F
+    F.ENABLED = fused
+    try:
+        if flat is not None:
+            flat.zero_grad()
+        else:
+            for p in block.parameters():
+                p.grad = None
+        xs = [t.clone().requires_grad_(True) for t in (x if isinstance(x, (list, tuple)) else [x])]
+        out = block(*xs)
+        out.backward(gy)
+        from hybrid_ctunet_amd import ops
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        grads = [p.grad.detach().clone() if p.grad is not None else None for p in block.parameters()]
+        return out.detach().clone(), [t.grad.detach().clone() for t in xs], grads
+    finally:
+        F.ENABLED = True
+
+
+def _close(a, b, name, tol=2e-2, same=0.98):
+    a, b = a.float(), b.float()
+    scale = b.abs().max().clamp_min(1e-12)
+    err = ((a - b).abs().max() / scale).item()
+    frac = (a == b).float().mean().item()
+    assert err <= tol, (name, err)
+    assert frac >= same, (name, "bit-equal fraction", frac)
+
+
+def _compare(block, xs_list, direct):
+    import hybrid_ctunet_amd as H
+    flat = H.FlatParams([p for p in block.parameters()]) if direct else None
+    try:
+        for rep, x in enumerate(xs_list):
+            first = x[0] if isinstance(x, (list, tuple)) else x
+            with torch.no_grad():
+                shape = block(*(x if isinstance(x, (list, tuple)) else [x])).shape
+            gy = torch.randn(shape, device="cuda").to(first.dtype)
+            ref = _run(block, x, gy, False, flat)
+            got = _run(block, x, gy, True, flat)
+            _close(got[0], ref[0], f"out[{rep}]")
+            for i, (a, b) in enumerate(zip(got[1], ref[1])):
+                _close(a, b, f"dx{i}[{rep}]", same=0.5)        # (split-K data gradients add with atomics)
+            for i, (a, b) in enumerate(zip(got[2], ref[2])):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    _close(a, b, f"dw{i}[{rep}]", tol=5e-3, same=0.0)   # (fp32 atomics: the summation order is not fixed)
+    finally:
+        if flat is not None:
+            flat.release()
+
+
+@pytest.mark.parametrize("direct", [False, True])
+@pytest.mark.parametrize("cfg", [
+    (64, 32, (1, 1, 1), True, (2, 12, 12, 24)),      # layer1.0: stride-1 downsample (1x1x1 as a plain GEMM)
+    (128, 32, (1, 1, 1), False, (2, 12, 12, 24)),    # identity shortcut
+    (128, 64, (2, 2, 2), True, (2, 12, 12, 24)),     # strided 3x3x3 + strided 1x1x1 downsample (generic implicit GEMM)
+    (256, 64, (1, 1, 1), False, (1, 6, 6, 12)),      # 432 voxels per item: statistics by a separate pass
+    (512, 128, (1, 1, 1), False, (2, 12, 12, 24)),
+])
+def test_bottleneck_fused_equals_per_op(cfg, direct):
+    from hybrid_ctunet_amd.networks import resnet as R
+    from hybrid_ctunet_amd import ops_fused as F
+    cin, planes, stride, down, vol = cfg
+    torch.manual_seed(0)
+    ds = R._Downsample(cin, planes * 4, stride) if down else None
+    blk = R.Bottleneck(cin, planes, stride=stride, downsample=ds).cuda()
+    xs = [torch.randn(*vol, cin, device="cuda").to(torch.bfloat16) for _ in range(2)]
+    assert F.bottleneck_ok(blk, xs[0])
+    _compare(blk, xs, direct)
+    assert any(k[0] == "bneck" for k in F._cache)
+
+
+def test_plan_replay_reports_the_failing_command():
+    """A launch list stops at the first failing entry point and says which one."""
+    from hybrid_ctunet_amd import _plan, _lib
+    R = _plan.Recorder(["a", "b"])
+    R.call("ctu_add", _lib.CTU_BF16, R["a"], R["b"], R["a"], 64)
+    R.call("ctu_add", 7, R["a"], R["b"], R["a"], 64)          # bad dtype code
+    plan = R.finish()
+    a = torch.ones(64, device="cuda", dtype=torch.bfloat16)
+    b = torch.ones(64, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="plan command 1"):
+        plan.run([a.data_ptr(), b.data_ptr()], [_lib.stream()])
+    torch.cuda.synchronize()
+    assert a.float().eq(2).all()
+
+
+@pytest.mark.parametrize("direct", [False, True])
+def test_vit_trunk_fused_equals_per_op(direct):
+    from hybrid_ctunet_amd.networks import vit as V
+    from hybrid_ctunet_amd import ops_fused as F
+    torch.manual_seed(0)
+
+    class Trunk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.transformer = torch.nn.ModuleList([V.TransformerBlock(256, 4, 64, 512) for _ in range(3)])
+            self.dropout = torch.nn.Dropout(0.0)
+
+        def forward(self, x):
+            if F.vit_trunk_ok(self, x):
+                return F.vit_trunk(self.transformer, x)
+            for b in self.transformer:
+                x = b(x)
+            return x
+
+    m = Trunk().cuda()
+    xs = [torch.randn(2, 432, 256, device="cuda").to(torch.bfloat16) for _ in range(2)]
+    _compare(m, xs, direct)
+    assert any(k[0] == "vit" for k in F._cache)
+
+
+@pytest.mark.parametrize("direct", [False, True])
+@pytest.mark.parametrize("ind,vol", [(0, (2, 6, 6, 12)), (1, (1, 12, 12, 24)), (2, (2, 12, 12, 24)), (3, (1, 12, 12, 24))])
+def test_up_attention_stage_fused_equals_per_op(ind, vol, direct):
+    """One UpAttentionBlock stage: block attention + FF + grid attention + FF + PixelShuffle (stage 3: FF + FF + shuffle)."""
+    from hybrid_ctunet_amd.networks import hybrid_CTUNet as N
+    from hybrid_ctunet_amd import ops_fused as F
+    torch.manual_seed(0)
+    up = N.UpAttentionBlock(3, 128, dims=[32, 64, 128, 256])   # stage widths 128, 128, 64, 32
+    blk = up.layers[ind][0]
+    c = blk[1].fn.norm.weight.shape[0] if ind <= 2 else blk[1].fn.net[0].weight.shape[0]
+
+    class Stage(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blk = blk
+
+        def forward(self, x):
+            return N.UpAttentionBlock._run_stage(self.blk, ind, x)
+
+    m = Stage().cuda()
+    xs = [torch.randn(*vol, c, device="cuda").to(torch.bfloat16) for _ in range(2)]
+    assert F.up_stage_ok(xs[0], blk, ind, True)
+    _compare(m, xs, direct)
+    assert any(k[0] == "upstage" for k in F._cache)

@@ -28,7 +28,33 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in ctunet_hip.h but not exported"
     assert sorted(_lib.EXPORTED) == declared, "python binding table and header disagree"
     lib.ctu_abi_version.restype = ctypes.c_int
-    assert lib.ctu_abi_version() == 5
+    assert lib.ctu_abi_version() == 6
+
+
+def test_plan_dispatch_table_is_current_and_packs_every_prototype():
+    """csrc/plan_dispatch.inc (the launch-list interpreter's switch) is generated from the header; the recorder packs argument
+    words by the same parse.  A plan can be recorded without a GPU: check the word layout of a call with inline structs."""
+    from hybrid_ctunet_amd import _plan
+    assert open(_plan.DISPATCH_INC).read() == _plan.emit_dispatch(), "run `python -m hybrid_ctunet_amd._plan --emit`"
+    assert len(_plan.SIGS) >= 40 and "ctu_adamw" not in _plan.SIGS and "ctu_plan_run" not in _plan.SIGS
+    for name, sig in _plan.SIGS.items():          # the binding table and the header parse agree on the argument count
+        assert len(sig) == len(_lib._SIGS[name]), name
+    R = _plan.Recorder(["x", "w", "y", "acc"], nstreams=2)
+    e = _lib.Epilogue()
+    e.ldc, e.in_rows = 64, 128
+    e._refs = {_lib.Epilogue.in_acc.offset: R["acc"] + 256}
+    R.call("ctu_igemm_nt", _lib.CTU_BF16, R["x"], None, R["w"], R["y"] + 1024, _lib.Geom(B=1, Di=4096, N=64), e, stream=1)
+    ev = R.new_event()
+    R.event_record(ev, 1)
+    R.stream_wait(0, ev)
+    assert R.words[0] == _plan.OPS["ctu_igemm_nt"] and R.words[1] == 1 and R.words[2] == 5 + 10 + 14
+    pos = {p[0]: (p[1], p[2]) for p in R.patches}
+    assert pos[3 + 1] == (0, 0) and pos[3 + 3] == (1, 0) and pos[3 + 4] == (2, 1024)
+    assert pos[3 + 5 + 10 + _lib.Epilogue.in_acc.offset // 8] == (3, 256)
+    assert R.words[3 + 5] & 0xFFFFFFFF == 1 and R.words[3 + 5] >> 32 == 4096      # ctu_geom inline: B, Di
+    assert R.words[-8:] == [_plan.OP_EVENT_RECORD, 1, 1, 0, _plan.OP_STREAM_WAIT, 0, 1, 0]
+    with pytest.raises(TypeError):
+        R.call("ctu_add", _lib.CTU_BF16, 12345, R["x"], R["y"], 64)     # a raw address cannot enter a plan
 
 
 def test_ctypes_struct_layouts_match_header():
