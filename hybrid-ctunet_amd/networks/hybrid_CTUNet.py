@@ -402,7 +402,7 @@ class _Base(nn.Module):
         if self.precision == "fp32":
             return torch.float32
         if torch.is_autocast_enabled():
-            dt = torch.get_autocast_gpu_dtype()
+            dt = torch.get_autocast_dtype('cuda')
             if dt == torch.float16:
                 if not _Base._warned_fp16:
                     _Base._warned_fp16 = True

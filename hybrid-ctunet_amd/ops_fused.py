@@ -358,14 +358,15 @@ class _BwdRun:
     def finish(self, w: _WS, n_norms: int, last_n: int, targets):
         w.par ^= n_norms & 1
         w.dirty_n = last_n
+        # "gradient complete", last layer first: the order the flat gradient buffer is laid out in (train.gradient_ready_order)
         if any(t[1] is not None for t in targets):
             if self.side is not None:
-                with torch.cuda.stream(self.side):   # "gradient complete" is reported on the stream that wrote it
-                    for t in targets:
+                with torch.cuda.stream(self.side):   # reported on the stream that wrote it
+                    for t in reversed(targets):
                         if t[1] is not None:
                             t[1]()
             else:
-                for t in targets:
+                for t in reversed(targets):
                     if t[1] is not None:
                         t[1]()
 
@@ -830,7 +831,9 @@ class PipeFn(torch.autograd.Function):
                [t.data_ptr() for t in bufs] + [ctx.out.data_ptr()] + [t.data_ptr() for t in G]
         run.keep_alive(x, gy, ctx.out, *bufs, *G)
         plan.run(vals, (run.s0, run.s1))
-        for t in targets:       # (main-stream and weight-gradient-stream gradients alike: whoever listens joins the side streams)
+        # "gradient complete", last layer first (the flat gradient buffer's order); main-stream and weight-gradient-stream
+        # gradients alike: whoever listens joins the side streams
+        for t in reversed(targets):
             if t[1] is not None:
                 t[1]()
         ctx.bufs = ctx.out = None
