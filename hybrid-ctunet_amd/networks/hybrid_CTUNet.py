@@ -51,6 +51,8 @@ class ResBlock(nn.Module):
             self.downsample = True
 
     def forward(self, inp, inp2=None, grad_stash=None):
+        if ops_fused.resblock_ok(self, inp, inp2, grad_stash):
+            return ops_fused.resblock(self, inp, inp2, grad_stash)   # one autograd node replayed from launch lists
         # grad_stash: a list another consumer of `inp` parks its gradient in (ops.GradStash, created AFTER this block); it is
         # added in the data-gradient epilogue of the first convolution of this block that autograd replays.
         # identity shortcut: its gradient is folded into conv1's data-gradient epilogue (ops.GradStash) instead of an
@@ -155,6 +157,8 @@ class pixelweight_attention(nn.Module):
         self.to_out = nn.Sequential(nn.Linear(dim, dim, bias=False), nn.Dropout(dropout))
 
     def forward(self, x1, x2):
+        if ops_fused.pwa_block_ok(self, x1, x2):
+            return ops_fused.pwa_block(self, x1, x2)   # one autograd node replayed from launch lists
         qkv1 = ops.linear(ops.layer_norm(x1, self.norm1.weight, self.norm1.bias), self.to_qkv1.weight)
         qkv2 = ops.linear(ops.layer_norm(x2, self.norm2.weight, self.norm2.bias), self.to_qkv2.weight)
         out = ops.pwa(qkv1, qkv2, self.scale)

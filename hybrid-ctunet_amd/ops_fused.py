@@ -937,3 +937,310 @@ def up_stage(blk, ind, x):
         params = _ff_params(blk[1].fn.net) + _ff_params(blk[2].fn.net)
     params += [sh.to_out.weight, sh.to_out.bias]
     return PipeFn.apply(x, pl, (B, D * f[0], H * f[1], W * f[2], cout), *params)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ResBlock (networks/hybrid_CTUNet.py:29-105), stride 1, optionally over a channel-concatenated pair of inputs
+# ---------------------------------------------------------------------------------------------------------------
+class _ResBlockPlan:
+    def __init__(self, B, D, H, W, C1, C2, N, has_down):
+        self.B, self.N, self.C1, self.C2, self.has_down = B, N, C1, C2, has_down
+        one, three = (1, 1, 1), (3, 3, 3)
+        self.c1 = ConvSpec(B, (D, H, W), C1, C2, N, three, one, one)
+        self.c2 = ConvSpec(B, (D, H, W), N, 0, N, three, one, one)
+        self.c3 = ConvSpec(B, (D, H, W), C1, C2, N, one, one, (0, 0, 0)) if has_down else None
+        if self.c1.kind != "halo" or self.c2.kind != "halo":
+            raise NotImplementedError("fused ResBlock: both 3x3x3 convolutions on the halo kernel")
+        self.a1_b16 = self.c2.wants_b16_input()
+        M = self.c1.Mo
+        self.S = self.c1.So
+        F = self.fbufs = _Bufs("F")
+        F.add("y1", M * N * 2), F.add("a1", M * N * 2), F.add("y2", M * N * 2)
+        if has_down:
+            F.add("y3", M * N * 2)
+        F.add("st", 3 * 8192 * 4)
+        F.add("mask", M * N // 8)
+        G = self.gbufs = _Bufs("G")
+        G.add("g2", M * N * 2), G.add("gres", M * N * 2), G.add("ga1", M * N * 2), G.add("g1", M * N * 2)
+        if has_down:
+            G.add("g3", M * N * 2), G.add("gs1", M * C1 * 2)
+            if C2:
+                G.add("gs2", M * C2 * 2)
+        assert B * N * 2 <= 8192
+        self.need = _Need()
+        self.fwd = None
+        self.bwd: Dict[tuple, object] = {}
+        self.out_shape = (B, D, H, W, N)
+
+    FWD_SLOTS = ("x1", "x2", "out", "rd", "w1", "w2", "w3") + WS_NAMES
+
+    def record_fwd(self):
+        R = Recorder(self.FWD_SLOTS + tuple(self.fbufs.slot_names()))
+        self.fbufs.bind(R)
+        B, N, S = self.B, self.N, self.S
+        c1, c2, c3 = self.c1, self.c2, self.c3
+        x2 = R["x2"] if self.C2 else None
+        st = [R["st"] + 32768 * i for i in range(3)]
+        need = self.need
+        f = em_conv_fwd(R, need, c1, R["x1"], x2, R["w1"], R["y1"])
+        em_in_fwd(R, R["y1"], st[0], R["a1"], B, S, N, fused=f, act=1, b16=self.a1_b16)
+        f = em_conv_fwd(R, need, c2, R["a1"], None, R["w2"], R["y2"], x1_b16=self.a1_b16)
+        if f:
+            R.call("ctu_in_finalize", B, S, N, R["inacc"], st[1])
+        else:
+            R.call("ctu_in_stats", BF16, R["y2"], B, S, N, R["inacc"], st[1])
+        res = R["x1"]
+        if c3 is not None:
+            f = em_conv_fwd(R, need, c3, R["x1"], x2, R["w3"], R["y3"])
+            em_in_fwd(R, R["y3"], st[2], R["rd"], B, S, N, fused=f, act=0)
+            res = R["rd"]
+        R.call("ctu_in_apply", BF16, R["y2"], st[1], res, R["out"], B, S, N, 1, 0, R["mask"])
+        self.fwd = R.finish()
+
+    BWD_SLOTS = ("x1", "x2", "gy", "gx1", "gx2", "ext", "w1d", "w2d", "w3d", "gw1", "gw2", "gw3") + BWD_WS_NAMES
+
+    def record_bwd(self, key):
+        need_w, side, has_ext = key
+        R = Recorder(self.BWD_SLOTS + tuple(self.fbufs.slot_names()) + tuple(self.gbufs.slot_names()), nstreams=2)
+        self.fbufs.bind(R)
+        self.gbufs.bind(R)
+        B, N, S = self.B, self.N, self.S
+        c1, c2, c3 = self.c1, self.c2, self.c3
+        x2 = R["x2"] if self.C2 else None
+        gx2 = R["gx2"] if self.C2 else None
+        st = [R["st"] + 32768 * i for i in range(3)]
+        need = self.need
+        nb = _InBwd(R)
+        # norm2 (+ residual + LeakyReLU)
+        nb.emit(R["gy"], R["y2"], None, st[1], R["g2"], R["gres"], B, S, N, 1, c2.gy_b16, R["mask"])
+        em_conv_dgrad(R, need, c2, R["g2"], R["w2d"], R["ga1"], None, gy_b16=c2.gy_b16)
+        if need_w[1]:
+            em_conv_wgrad(R, need, c2, R["g2"], R["a1"], None, R["gw2"], stream=_wg_stream(R, side), x1_b16=self.a1_b16,
+                          gy_b16=c2.gy_b16)
+        nb.emit(R["ga1"], R["y1"], None, st[0], R["g1"], None, B, S, N, 1, c1.gy_b16)
+        ext = R["ext"] if has_ext else None
+        if c3 is not None:
+            # conv shortcut: norm3 (no activation) -> conv3's data gradients, folded into conv1's data-gradient epilogue
+            nb.emit(R["gres"], R["y3"], None, st[2], R["g3"], None, B, S, N, 0, 0)
+            gs2 = R["gs2"] if self.C2 else None
+            em_conv_dgrad(R, need, c3, R["g3"], R["w3d"], R["gs1"], gs2, extra=ext)
+            if need_w[2]:
+                em_conv_wgrad(R, need, c3, R["g3"], R["x1"], x2, R["gw3"], stream=_wg_stream(R, side))
+            em_conv_dgrad(R, need, c1, R["g1"], R["w1d"], R["gx1"], gx2, extra=R["gs1"], extra2=gs2, gy_b16=c1.gy_b16)
+        else:
+            assert not has_ext
+            em_conv_dgrad(R, need, c1, R["g1"], R["w1d"], R["gx1"], gx2, extra=R["gres"], gy_b16=c1.gy_b16)
+        if need_w[0]:
+            em_conv_wgrad(R, need, c1, R["g1"], R["x1"], x2, R["gw1"], stream=_wg_stream(R, side), gy_b16=c1.gy_b16)
+        self.n_norms, self.last_n = nb.k, nb.prev
+        self.bwd[key] = R.finish()
+        return self.bwd[key]
+
+
+class ResBlockFn(torch.autograd.Function):
+    """ResBlock.forward (networks/hybrid_CTUNet.py:93-105) as one autograd node; x2 = second half of a channel concat
+    (torch.cat at :199,618) or None; w3 = the 1x1x1 shortcut convolution's weight when in != out channels, else None.
+    grad_stash: a list another consumer of x1 parks its gradient in (ops.GradStash); it joins conv3's data gradient."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w1, w2, w3, grad_stash):
+        B, D, H, W, C1 = x1.shape
+        C2 = x2.shape[-1] if x2 is not None else 0
+        N = w1.shape[0]
+        key = ("resblock", B, D, H, W, C1, C2, N, w3 is not None, _flags())
+        pl = _cache.get(key)
+        if pl is None:
+            pl = _cache[key] = _ResBlockPlan(B, D, H, W, C1, C2, N, w3 is not None)
+        if pl.fwd is None:
+            pl.record_fwd()
+        dev = x1.device
+        out = torch.empty(pl.out_shape, dtype=x1.dtype, device=dev)
+        bufs = pl.fbufs.alloc(dev)
+        rd = torch.empty(pl.out_shape, dtype=x1.dtype, device=dev) if w3 is not None else None
+        w1f = conv_weights(pl.c1, w1, dgrad=False)[0]
+        w2f = conv_weights(pl.c2, w2, dgrad=False)[0]
+        w3f = conv_weights(pl.c3, w3, dgrad=False)[0] if w3 is not None else None
+        sid = L.stream()
+        vals = [x1.data_ptr(), x2.data_ptr() if x2 is not None else 0, out.data_ptr(), rd.data_ptr() if rd is not None else 0,
+                w1f.data_ptr(), w2f.data_ptr(), w3f.data_ptr() if w3f is not None else 0] + \
+            _fwd_ws_values(dev, sid, pl.need) + [t.data_ptr() for t in bufs]
+        pl.fwd.run(vals, (sid,))
+        ctx.pl, ctx.bufs, ctx.grad_stash = pl, bufs, grad_stash
+        ctx.save_for_backward(x1, x2, w1, w2, w3)
+        for i, w in enumerate((w1, w2, w3)):
+            ops.sink_expect(w, ctx.needs_input_grad[2 + i])
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x1, x2, w1, w2, w3 = ctx.saved_tensors
+        pl, bufs = ctx.pl, ctx.bufs
+        gy = gy.contiguous()
+        dev = x1.device
+        weights = (w1, w2, w3)
+        need_w = tuple(bool(ctx.needs_input_grad[2 + i]) and w is not None for i, w in enumerate(weights))
+        targets = _grad_targets(weights, need_w)
+        run = _BwdRun(dev, targets)
+        ext = ops._take(ctx.grad_stash)
+        if ext is not None and (ext.shape != x1.shape or ext.dtype != x1.dtype or not ext.is_contiguous()):
+            ext = ext.to(x1.dtype).contiguous().view_as(x1)
+        if ext is not None and w3 is None:
+            raise NotImplementedError("an outside gradient stash and an identity shortcut share conv1's one residual input")
+        key = (need_w, run.side is not None, ext is not None)
+        plan = pl.bwd.get(key) or pl.record_bwd(key)
+        gx1 = torch.empty_like(x1)
+        gx2 = torch.empty_like(x2) if x2 is not None else None
+        G = pl.gbufs.alloc(dev)
+        wds = [conv_weights(s, w, fwd=False)[1] if w is not None else None for s, w in zip((pl.c1, pl.c2, pl.c3), weights)]
+        wsv, w = run.ws_values(pl.need)
+        vals = [x1.data_ptr(), x2.data_ptr() if x2 is not None else 0, gy.data_ptr(), gx1.data_ptr(),
+                gx2.data_ptr() if gx2 is not None else 0, ext.data_ptr() if ext is not None else 0] + \
+               [t.data_ptr() if t is not None else 0 for t in wds] + \
+               [t[0].data_ptr() if t[0] is not None else 0 for t in targets] + wsv + \
+               [t.data_ptr() for t in bufs] + [t.data_ptr() for t in G]
+        run.keep_alive(x1, x2, *bufs, *G)
+        plan.run(vals, (run.s0, run.s1))
+        run.finish(w, pl.n_norms, pl.last_n, targets)
+        ctx.bufs = None
+        return (gx1, gx2) + tuple(t[2] for t in targets) + (None,)
+
+
+def resblock_ok(blk, x1, x2, grad_stash) -> bool:
+    if not usable(x1) or x1.dim() != 5 or (x2 is not None and not (x2.is_contiguous() and x2.dtype == x1.dtype)):
+        return False
+    c1 = blk.conv1
+    if c1.kernel_size != (3, 3, 3) or c1.stride != (1, 1, 1) or blk.conv2.kernel_size != (3, 3, 3):
+        return False
+    C1, C2, N = x1.shape[-1], (x2.shape[-1] if x2 is not None else 0), c1.out_channels
+    if C1 % 32 or C2 % 32 or N % 32 or x1.numel() // C1 * max(C1, C2, N) >= (1 << 31):
+        return False
+    if not blk.downsample and (grad_stash is not None or x2 is not None):
+        return False
+    return True
+
+
+def resblock(blk, x1, x2, grad_stash):
+    w3 = blk.conv3.conv.weight if blk.downsample else None
+    return ResBlockFn.apply(x1, x2, blk.conv1.conv.weight, blk.conv2.conv.weight, w3, grad_stash)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# pixelweight_attention: binary cross-weight fusion (networks/hybrid_CTUNet.py:622-669)
+# ---------------------------------------------------------------------------------------------------------------
+class _PwaPlan:
+    PNAMES = ("g1", "b1", "g2", "b2", "wq1", "wq2", "wo")
+    LIN = (False, False, False, False, True, True, True)
+
+    def __init__(self, M, C, scale):
+        self.M, self.C, self.scale = M, C, float(scale)
+        F = self.F = _Bufs("F")
+        for i in (1, 2):
+            F.add(f"h{i}", M * C * 2), F.add(f"mr{i}", M * 8), F.add(f"qkv{i}", M * 3 * C * 2)
+        F.add("o", M * C * 2)
+        G = self.G = _Bufs("G")
+        G.add("go", M * C * 2)
+        for i in (1, 2):
+            G.add(f"gq{i}", M * 3 * C * 2), G.add(f"gh{i}", M * C * 2)
+        self.need = _Need()
+        self.fwd = None
+        self.bwd: Dict[tuple, object] = {}
+        self.t_names = [n + ".t" for n, bad in (("wq1", (3 * C) % 64 or C % 8), ("wq2", (3 * C) % 64 or C % 8), ("wo", C % 64 or C % 8)) if bad]
+
+    def record_fwd(self):
+        R = Recorder(["x1", "x2", "out"] + list(self.PNAMES) + ["skws"] + self.F.slot_names())
+        self.F.bind(R)
+        M, C = self.M, self.C
+        for i in (1, 2):
+            R.call("ctu_layernorm_fwd", BF16, R[f"x{i}"], R[f"g{i}"], R[f"b{i}"], R[f"h{i}"], R[f"mr{i}"], M, C)
+            em_gemm(R, self.need, R[f"h{i}"], R[f"wq{i}"], R[f"qkv{i}"], M, C, 3 * C)
+        R.call("ctu_pwa_fwd", BF16, R["qkv1"], R["qkv2"], R["o"], M, C, self.scale)
+        em_gemm(R, self.need, R["o"], R["wo"], R["out"], M, C, C)
+        self.fwd = R.finish()
+
+    def record_bwd(self, side):
+        gnames = [p + ".g" for p in self.PNAMES]
+        R = Recorder(["x1", "x2", "gy", "gx1", "gx2"] + list(self.PNAMES) + self.t_names + gnames + ["skws", "tnws1", "lnws"] +
+                     self.F.slot_names() + self.G.slot_names(), nstreams=2)
+        self.F.bind(R)
+        self.G.bind(R)
+        M, C = self.M, self.C
+        t = lambda n: R[n + ".t"] if R.has(n + ".t") else None   # noqa: E731
+        _lin_dgrad(R, self.need, R["gy"], R["wo"], t("wo"), R["go"], M, C, C)
+        _lin_wgrad(R, R["gy"], R["o"], R["wo.g"], None, M, C, C, _wg_stream(R, side))
+        R.call("ctu_pwa_bwd", BF16, R["qkv1"], R["qkv2"], R["go"], R["gq1"], R["gq2"], M, C, self.scale)
+        for i in (2, 1):
+            _lin_dgrad(R, self.need, R[f"gq{i}"], R[f"wq{i}"], t(f"wq{i}"), R[f"gh{i}"], M, 3 * C, C)
+            _lin_wgrad(R, R[f"gq{i}"], R[f"h{i}"], R[f"wq{i}.g"], None, M, 3 * C, C, _wg_stream(R, side))
+            R.call("ctu_layernorm_bwd_add", BF16, R[f"gh{i}"], R[f"x{i}"], R[f"g{i}"], R[f"mr{i}"], None, R[f"gx{i}"],
+                   R[f"g{i}.g"], R[f"b{i}.g"], R["lnws"], M, C)
+        self.bwd[side] = R.finish()
+        return self.bwd[side]
+
+
+class PwaBlockFn(torch.autograd.Function):
+    """pixelweight_attention.forward (hybrid_CTUNet.py:645-669): to_out(cross_weight(to_qkv1(LN1(x1)), to_qkv2(LN2(x2))))."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, scale, *params):
+        C = x1.shape[-1]
+        M = x1.numel() // C
+        key = ("pwa", M, C, float(scale), _flags())
+        pl = _cache.get(key)
+        if pl is None:
+            pl = _cache[key] = _PwaPlan(M, C, scale)
+        if pl.fwd is None:
+            pl.record_fwd()
+        dev = x1.device
+        out = torch.empty_like(x1)
+        bufs = pl.F.alloc(dev)
+        pv = [(ops._linear_weight(p, p, torch.bfloat16) if lin else p).data_ptr() for p, lin in zip(params, pl.LIN)]
+        sid = L.stream()
+        vals = [x1.data_ptr(), x2.data_ptr(), out.data_ptr()] + pv + [ops._splitk_workspace(dev, pl.need.skws).data_ptr()] + \
+               [t.data_ptr() for t in bufs]
+        pl.fwd.run(vals, (sid,))
+        ctx.pl, ctx.bufs = pl, bufs
+        ctx.save_for_backward(x1, x2, *params)
+        for i, p in enumerate(params):
+            ops.sink_expect(p, ctx.needs_input_grad[3 + i])
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x1, x2, *params = ctx.saved_tensors
+        pl, bufs = ctx.pl, ctx.bufs
+        gy = gy.contiguous()
+        dev = x1.device
+        need_w = [bool(ctx.needs_input_grad[3 + i]) for i in range(len(params))]
+        if not all(need_w):
+            raise NotImplementedError("fused cross-weight block: every parameter is expected to require a gradient")
+        targets = _grad_targets(params, need_w)
+        run = _BwdRun(dev, targets)
+        side = run.side is not None
+        plan = pl.bwd.get(side) or pl.record_bwd(side)
+        gx1, gx2 = torch.empty_like(x1), torch.empty_like(x2)
+        G = pl.G.alloc(dev)
+        pv = [(ops._linear_weight(p, p, torch.bfloat16) if lin else p).data_ptr() for p, lin in zip(params, pl.LIN)]
+        tv = [ops._packed(params[pl.PNAMES.index(n[:-2])], "lin_d", torch.bfloat16,
+                          lambda p=params[pl.PNAMES.index(n[:-2])]: p.detach().t().to(torch.bfloat16).contiguous()).data_ptr()
+              for n in pl.t_names]
+        key1 = (dev, run.s1, ops._ws_epoch)
+        vals = [x1.data_ptr(), x2.data_ptr(), gy.data_ptr(), gx1.data_ptr(), gx2.data_ptr()] + pv + tv + \
+               [t[0].data_ptr() for t in targets] + \
+               [ops._splitk_workspace(dev, pl.need.skws).data_ptr(), _tn_ws_for(key1).data_ptr(), _lnws(dev, run.s0).data_ptr()] + \
+               [t.data_ptr() for t in bufs] + [t.data_ptr() for t in G]
+        run.keep_alive(x1, x2, gy, *bufs, *G)
+        plan.run(vals, (run.s0, run.s1))
+        for t in reversed(targets):
+            if t[1] is not None:
+                t[1]()
+        ctx.bufs = None
+        return (gx1, gx2, None) + tuple(t[2] for t in targets)
+
+
+def pwa_block_ok(m, x1, x2) -> bool:
+    return usable(x1) and x2.is_contiguous() and x2.dtype == x1.dtype and x1.shape == x2.shape and x1.shape[-1] % 32 == 0
+
+
+def pwa_block(m, x1, x2):
+    return PwaBlockFn.apply(x1, x2, m.scale, m.norm1.weight, m.norm1.bias, m.norm2.weight, m.norm2.bias, m.to_qkv1.weight,
+                            m.to_qkv2.weight, m.to_out[0].weight)

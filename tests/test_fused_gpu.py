@@ -146,3 +146,60 @@ def test_up_attention_stage_fused_equals_per_op(ind, vol, direct):
     assert F.up_stage_ok(xs[0], blk, ind, True)
     _compare(m, xs, direct)
     assert any(k[0] == "upstage" for k in F._cache)
+
+
+@pytest.mark.parametrize("direct", [False, True])
+@pytest.mark.parametrize("cin,cin2,cout,vol", [(64, 0, 64, (2, 12, 12, 24)),      # identity shortcut
+                                                (64, 64, 64, (1, 12, 16, 24)),     # CatConvBlock: concat + conv shortcut
+                                                (128, 128, 128, (2, 6, 6, 12))])   # small volume: channel-split halo kernels
+def test_resblock_fused_equals_per_op(cin, cin2, cout, vol, direct):
+    from hybrid_ctunet_amd.networks import hybrid_CTUNet as N
+    from hybrid_ctunet_amd import ops_fused as F
+    torch.manual_seed(0)
+    blk = N.ResBlock(3, cin + cin2, cout, 3, 1, "instance").cuda()
+    mk = lambda c: torch.randn(*vol, c, device="cuda").to(torch.bfloat16)  # noqa: E731
+    xs = [[mk(cin)] + ([mk(cin2)] if cin2 else []) for _ in range(2)]
+    assert F.resblock_ok(blk, xs[0][0], xs[0][1] if cin2 else None, None)
+    _compare(blk, xs, direct)
+    assert any(k[0] == "resblock" for k in F._cache)
+
+
+def test_resblock_fused_takes_an_outside_gradient_stash():
+    """vit_decoder0: the 96x96 head reads the same tensor as the block's first input; its gradient is parked (ops.GradStash)
+    and must come out of the fused block's backward added to that input's gradient."""
+    from hybrid_ctunet_amd.networks import hybrid_CTUNet as N
+    from hybrid_ctunet_amd import ops, ops_fused as F
+    torch.manual_seed(0)
+    blk = N.ResBlock(3, 128, 64, 3, 1, "instance").cuda()
+    a = torch.randn(1, 12, 12, 24, 64, device="cuda").to(torch.bfloat16)
+    b = torch.randn(1, 12, 12, 24, 64, device="cuda").to(torch.bfloat16)
+    gy = torch.randn(1, 12, 12, 24, 64, device="cuda").to(torch.bfloat16)
+    gh = torch.randn(1, 12, 12, 24, 64, device="cuda").to(torch.bfloat16)
+    res = []
+    for fused in (False, True):
+        F.ENABLED = fused
+        try:
+            a1, b1 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            st = []
+            out = blk(a1, b1, grad_stash=st)
+            side = ops.GradStash.apply(a1, st)
+            torch.autograd.backward([out, side], [gy, gh])
+            torch.cuda.synchronize()
+            res.append((a1.grad.clone(), b1.grad.clone()))
+        finally:
+            F.ENABLED = True
+    _close(res[1][0], res[0][0], "dx1 with stash", same=0.5)
+    _close(res[1][1], res[0][1], "dx2", same=0.5)
+
+
+@pytest.mark.parametrize("direct", [False, True])
+@pytest.mark.parametrize("dim,vol", [(128, (2, 12, 12, 24)), (512, (1, 6, 6, 12))])
+def test_cross_weight_block_fused_equals_per_op(dim, vol, direct):
+    from hybrid_ctunet_amd.networks import hybrid_CTUNet as N
+    from hybrid_ctunet_amd import ops_fused as F
+    torch.manual_seed(0)
+    m = N.pixelweight_attention(dim).cuda()
+    xs = [[torch.randn(*vol, dim, device="cuda").to(torch.bfloat16) for _ in range(2)] for _ in range(2)]
+    assert F.pwa_block_ok(m, *xs[0])
+    _compare(m, xs, direct)
+    assert any(k[0] == "pwa" for k in F._cache)
