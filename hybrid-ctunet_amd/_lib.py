@@ -48,6 +48,8 @@ _SIGS = {
     "ctu_conv3_halo": [_i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 10 + [_vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "ctu_in_finalize": [_i32, _i64, _i32, _vp, _vp, _vp],
     "ctu_conv3_halo_wgrad": [_i32, _vp, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _i64, _vp],
+    "ctu_conv3_halo_wgrad_param": [_i32, _vp, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _i64, _vp],
+    "ctu_in_apply_acc": [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
     "ctu_pack_frag": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp],
     "ctu_pack_frag_batched": [_vp, _i32, _i64, _vp],
     "ctu_im2col_cin1": [_vp, _vp, C.POINTER(Geom), _i32, _vp],

@@ -1123,10 +1123,48 @@ __global__ __launch_bounds__(256) void halo_wgrad_reduce_kernel(const float* __r
   }
 }
 
+// Sum of the per-split partial panels part[split][27][NK], ADDED into the parameter layout dw[NK][27].  Workgroup (x, t) owns
+// 64 consecutive (n, k) pairs of tap t: the four waves share the splits (256 contiguous bytes per read), one LDS exchange,
+// then 64 read-modify-writes 108 bytes apart.  The partials are the traffic (splits x panel: 57 MB at 64 -> 64 @ 96^3, 128
+// splits), so the grid has to be wide - NK / 64 x 27 workgroups; the scattered 4-byte updates are a few hundred KB.
+__global__ __launch_bounds__(256) void halo_wgrad_reduce_param_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                       const int64_t NK, const int splits) {
+  __shared__ float red[3][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int t = blockIdx.y;
+  const int64_t nk = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t panel = 27 * NK;
+  float a = 0.f;
+  if (nk < NK) {
+    const float* src = part + (int64_t)t * NK + nk;
+#pragma unroll 8
+    for (int sp = g; sp < splits; sp += 4) a += src[(int64_t)sp * panel];
+  }
+  if (g > 0) red[g - 1][lane] = a;
+  __syncthreads();
+  if (g == 0 && nk < NK) dw[nk * 27 + t] += a + red[0][lane] + red[1][lane] + red[2][lane];
+}
+
+static int halo_wgrad_impl(ctu_dtype dtype, const void* dy, const void* x1, const void* x2, float* dw, int32_t B,
+                           int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N,
+                           int32_t x1_layout, int32_t dy_layout, float* ws, int64_t ws_floats,
+                           ctu_stream_t stream, const bool param_layout);
 extern "C" int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void* x1, const void* x2, float* dw, int32_t B,
                                     int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N,
                                     int32_t x1_layout, int32_t dy_layout, float* ws, int64_t ws_floats,
                                     ctu_stream_t stream) {
+  return halo_wgrad_impl(dtype, dy, x1, x2, dw, B, D, H, W, C1, C2, N, x1_layout, dy_layout, ws, ws_floats, stream, false);
+}
+extern "C" int ctu_conv3_halo_wgrad_param(ctu_dtype dtype, const void* dy, const void* x1, const void* x2, float* dw_param,
+                                          int32_t B, int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N,
+                                          int32_t x1_layout, int32_t dy_layout, float* ws, int64_t ws_floats,
+                                          ctu_stream_t stream) {
+  return halo_wgrad_impl(dtype, dy, x1, x2, dw_param, B, D, H, W, C1, C2, N, x1_layout, dy_layout, ws, ws_floats, stream, true);
+}
+static int halo_wgrad_impl(ctu_dtype dtype, const void* dy, const void* x1, const void* x2, float* dw, int32_t B,
+                           int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N,
+                           int32_t x1_layout, int32_t dy_layout, float* ws, int64_t ws_floats,
+                           ctu_stream_t stream, const bool param_layout) {
   CTU_REQUIRE(dy && x1 && dw, "conv3_halo_wgrad: null pointer");
   CTU_REQUIRE(ws_floats >= 0 && (ws_floats == 0 || ws), "conv3_halo_wgrad: bad workspace");
   CTU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3_halo_wgrad: bad dims");
@@ -1165,8 +1203,11 @@ extern "C" int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void*
     splits = (p.nbricks + p.bricks_per_block - 1) / p.bricks_per_block;
     CTU_REQUIRE((int64_t)tiles * splits < (1ll << 31), "conv3_halo_wgrad: too many workgroups");
     const int64_t panel = (int64_t)27 * N * (C1 + C2);
-    const bool partials = splits > 1 && ws && (int64_t)splits * panel <= ws_floats && (C1 + C2) % 4 == 0 &&
-                          !(ctu_option_route() & CTU_ROUTE_HALO_WGRAD_ATOMICS);
+    const bool partials = param_layout ||
+                          (splits > 1 && ws && (int64_t)splits * panel <= ws_floats && (C1 + C2) % 4 == 0 &&
+                           !(ctu_option_route() & CTU_ROUTE_HALO_WGRAD_ATOMICS));
+    CTU_REQUIRE(!param_layout || (ws && (int64_t)splits * panel <= ws_floats),
+                "conv3_halo_wgrad_param: workspace of %lld floats needed", (long long)splits * panel);
     if (partials) p.part = ws;
     if ((p.debug & 16) && partials && ntn == 2 && ws_floats >= (int64_t)splits * panel + (int64_t)tiles * splits * 8 * 8 * 2) {  // diagnostic build
       p.stamps = ws + (int64_t)splits * panel;
@@ -1178,7 +1219,10 @@ extern "C" int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void*
     else if (ntn == 2) hipLaunchKernelGGL(conv3_halo_wgrad_dma_kernel<2>, dim3(tiles * splits), dim3(512), 0, s, p);
     else if (burst) hipLaunchKernelGGL((conv3_halo_wgrad_dma_kernel<1, true>), dim3(tiles * splits), dim3(512), 0, s, p);
     else hipLaunchKernelGGL(conv3_halo_wgrad_dma_kernel<1>, dim3(tiles * splits), dim3(512), 0, s, p);
-    if (partials) {
+    if (partials && param_layout) {
+      const int64_t NK = (int64_t)N * (C1 + C2);
+      hipLaunchKernelGGL(halo_wgrad_reduce_param_kernel, dim3((unsigned)((NK + 63) / 64), 27), dim3(256), 0, s, ws, dw, NK, splits);
+    } else if (partials) {
       if (panel >= 4 * 64 * 1024)
         hipLaunchKernelGGL(halo_wgrad_reduce_kernel<4>, dim3((unsigned)((panel / 4 + 63) / 64)), dim3(256), 0, s, ws, dw, panel, splits);
       else
@@ -1186,6 +1230,7 @@ extern "C" int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void*
     }
     return ctu_check_launch("conv3_halo_wgrad");
   }
+  CTU_REQUIRE(!param_layout, "conv3_halo_wgrad_param: bf16 LDS-DMA kernel only");
   p.tiles_n = (N + 31) / 32;
   const int tiles = p.tiles_n * p.tiles_c;
   int splits = (512 + tiles - 1) / tiles;  // ~2 resident workgroups per CU

@@ -92,19 +92,44 @@ __device__ __forceinline__ void in_mean_rstd(const float* stats, int b, int C, i
 
 // y = act((x - mean) * rstd + residual).  grid (gx, B) with gx * 256 a multiple of C/8: a thread keeps ONE 8-channel
 // column group of ONE batch item, so mean / rstd are loaded once and the loop is a pure stream.
+// raw (optional): UNSHIFTED fp64 sums (sum x, sum x^2) [B][C][2] left by the producer's epilogue: (mean, rstd) are then
+// derived here - every thread for its own eight channels - and written to `stats` by the first workgroup of each batch item
+// (the separate finalize launch disappears); `clear` (optional, another accumulator no launch still reads) is zeroed.
 template <typename T>
-__global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+__global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, float* __restrict__ stats,
                                                        const T* __restrict__ res, T* __restrict__ y, const int64_t S,
                                                        const int C, const int act, const int64_t yb16,
-                                                       uint8_t* __restrict__ mask) {
+                                                       uint8_t* __restrict__ mask, const double* __restrict__ raw = nullptr,
+                                                       double* __restrict__ clear = nullptr, const int clear_n = 0) {
   const int ncg = C >> 3;
   const int b = blockIdx.y;
   const int64_t nvec = S * ncg;
   const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * 256;
+  if (clear && b == 0)
+    for (int64_t i = i0; i < clear_n; i += stride) clear[i] = 0.0;
   const int cg = (int)(i0 % ncg);
   float mean[8], rstd[8];
-  in_mean_rstd(stats, b, C, cg * 8, 0.f, mean, rstd);
+  if (raw) {
+    const double inv_s = 1.0 / (double)S;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const size_t o = ((size_t)b * C + cg * 8 + e) * 2;
+      const double m = raw[o] * inv_s;
+      const double var = fmax(raw[o + 1] * inv_s - m * m, 0.0);
+      mean[e] = (float)m;
+      rstd[e] = (float)(1.0 / sqrt(var + (double)NORM_EPS));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < ncg) {   // (grid.x * 256 is a multiple of ncg: thread t of block 0 holds column group t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        stats[((size_t)b * C + cg * 8 + e) * 2] = mean[e];
+        stats[((size_t)b * C + cg * 8 + e) * 2 + 1] = rstd[e];
+      }
+    }
+  } else {
+    in_mean_rstd(stats, b, C, cg * 8, 0.f, mean, rstd);
+  }
   const size_t base = (size_t)b * S * C;
   x += base;
   // yb16 > 0 (= voxels of the whole batch): y in CTU_LAYOUT_B16, element (m, c) at ((c >> 4) * yb16 + m) * 16 + (c & 15)
@@ -353,21 +378,33 @@ extern "C" int ctu_in_finalize(int32_t B, int64_t S, int32_t C, double* acc, flo
   return ctu_check_launch("in_finalize");
 }
 
-extern "C" int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, const void* residual, void* y,
-                            int32_t B, int64_t S, int32_t C, int32_t act, int32_t y_layout, uint8_t* sign_mask,
-                            ctu_stream_t stream) {
+static int in_apply_impl(ctu_dtype dtype, const void* x, const double* raw, float* stats, const void* residual, void* y,
+                         int32_t B, int64_t S, int32_t C, int32_t act, int32_t y_layout, uint8_t* sign_mask,
+                         double* clear_ws, int32_t clear_n, ctu_stream_t stream) {
   if (int rc = check_in(x, B, S, C)) return rc;
   CTU_REQUIRE(stats && y, "null pointer");
   CTU_REQUIRE(y_layout == CTU_LAYOUT_NDHWC || (y_layout == CTU_LAYOUT_B16 && C % 16 == 0 && y != x), "in_apply: bad output layout");
+  CTU_REQUIRE(clear_n >= 0 && (clear_n == 0 || clear_ws) && (clear_ws == nullptr || clear_ws != raw), "in_apply: bad clear workspace");
   const int64_t yb16 = y_layout == CTU_LAYOUT_B16 ? (int64_t)B * S : 0;
   const dim3 grid(in_stream_grid(S, C, B), B);
   hipStream_t s = (hipStream_t)stream;
   CTU_DISPATCH(dtype,
                hipLaunchKernelGGL(in_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, stats,
-                                  (const float*)residual, (float*)y, S, C, act, yb16, sign_mask),
+                                  (const float*)residual, (float*)y, S, C, act, yb16, sign_mask, raw, clear_ws, clear_n),
                hipLaunchKernelGGL(in_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, stats,
-                                  (const bf16*)residual, (bf16*)y, S, C, act, yb16, sign_mask));
+                                  (const bf16*)residual, (bf16*)y, S, C, act, yb16, sign_mask, raw, clear_ws, clear_n));
   return ctu_check_launch("in_apply");
+}
+extern "C" int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, const void* residual, void* y,
+                            int32_t B, int64_t S, int32_t C, int32_t act, int32_t y_layout, uint8_t* sign_mask,
+                            ctu_stream_t stream) {
+  return in_apply_impl(dtype, x, nullptr, const_cast<float*>(stats), residual, y, B, S, C, act, y_layout, sign_mask, nullptr, 0,
+                       stream);
+}
+extern "C" int ctu_in_apply_acc(ctu_dtype dtype, const void* x, const double* raw_acc, float* stats, const void* residual,
+                                void* y, int32_t B, int64_t S, int32_t C, int32_t act, int32_t y_layout,
+                                uint8_t* sign_mask, double* clear_ws, int32_t clear_n, ctu_stream_t stream) {
+  return in_apply_impl(dtype, x, raw_acc, stats, residual, y, B, S, C, act, y_layout, sign_mask, clear_ws, clear_n, stream);
 }
 
 extern "C" int ctu_in_bwd_reduce(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,

@@ -51,13 +51,17 @@ def _flags():
 # per-(device, stream) state of the fused path
 # ---------------------------------------------------------------------------------------------------------------
 class _WS:
-    __slots__ = ("inacc", "sums", "par", "dirty_n")
+    __slots__ = ("acc", "apar", "adirty", "sums", "par", "dirty_n")
 
     def __init__(self, device):
-        self.inacc = torch.zeros(1 << 14, dtype=torch.float64, device=device)    # fused IN statistics: zero between uses
-        self.sums = [torch.zeros(1 << 14, dtype=torch.float64, device=device) for _ in range(2)]  # IN backward sums
-        self.par = 0        # index of the clean sums buffer
-        self.dirty_n = 0    # entries the last backward left dirty in the other one
+        # InstanceNorm forward statistics: two fp64 accumulators alternate from norm to norm - a producer's epilogue sums into
+        # the clean one, the norm's apply kernel reads it and zeroes the other (ctu_in_apply_acc: no finalize launch)
+        self.acc = [torch.zeros(1 << 14, dtype=torch.float64, device=device) for _ in range(2)]
+        self.apar = 0       # index of the clean accumulator
+        self.adirty = 0     # entries the last norm left dirty in the other one
+        self.sums = [torch.zeros(1 << 14, dtype=torch.float64, device=device) for _ in range(2)]  # IN backward sums, same scheme
+        self.par = 0
+        self.dirty_n = 0
 
 
 _FWS: Dict[tuple, _WS] = {}
@@ -149,13 +153,28 @@ def em_gemm(R: Recorder, need: _Need, x, w, out, M, K, N, *, bias=None, residual
     R.call("ctu_igemm_nt", BF16, x, None, w, out, ops._plain_geom(M, K, N), e, stream=stream)
 
 
-def em_in_fwd(R: Recorder, y, stats, out, B, S, C, *, fused: bool, residual=None, act=1, b16=0, mask=None):
-    """ops.InstanceNormFn.forward: statistics (from the producer's epilogue sums, or a pass over y) + apply."""
-    if fused:
-        R.call("ctu_in_finalize", B, S, C, R["inacc"], stats)
-    else:
-        R.call("ctu_in_stats", BF16, y, B, S, C, R["inacc"], stats)
-    R.call("ctu_in_apply", BF16, y, stats, residual, out, B, S, C, int(act), int(b16), mask)
+class _InFwd:
+    """ops.InstanceNormFn.forward for the k-th norm of a forward plan.  `acc()` is the accumulator the norm's producer sums
+    into from its epilogue; the apply kernel derives (mean, rstd) from it and zeroes the other accumulator (the previous
+    norm's).  A producer without fused sums gets a statistics pass over its output instead."""
+
+    def __init__(self, R: Recorder):
+        self.R, self.k, self.prev = R, 0, None
+
+    def acc(self):
+        return self.R["ia0"] if self.k % 2 == 0 else self.R["ia1"]
+
+    def emit(self, y, stats, out, B, S, C, *, fused: bool, residual=None, act=1, b16=0, mask=None):
+        R = self.R
+        acc, other = (R["ia0"], R["ia1"]) if self.k % 2 == 0 else (R["ia1"], R["ia0"])
+        clear_n = R.ival("iadirty") if self.k == 0 else self.prev
+        if not fused:
+            R.call("ctu_in_stats", BF16, y, B, S, C, acc, stats)     # (leaves its accumulator zeroed)
+        R.call("ctu_in_apply_acc", BF16, y, acc if fused else None, stats, residual, out, B, S, C, int(act), int(b16), mask,
+               other, clear_n)
+        self.k += 1
+        self.prev = B * C * 2
+        assert self.prev <= (1 << 14)
 
 
 class _InBwd:
@@ -228,16 +247,16 @@ def conv_weights(spec: ConvSpec, weight, fwd=True, dgrad=True):
     return wf, wd
 
 
-def em_conv_fwd(R, need, spec: ConvSpec, x1, x2, w, out, *, x1_b16=0):
-    """ops.LinearFn / ops.ConvFn forward of `spec`; returns whether the InstanceNorm sums of `out` are in R["inacc"]."""
+def em_conv_fwd(R, need, spec: ConvSpec, x1, x2, w, out, *, x1_b16=0, acc=None):
+    """ops.LinearFn / ops.ConvFn forward of `spec`; returns whether the InstanceNorm sums of `out` were added into `acc`."""
     s = spec
     if s.kind == "lin":
-        em_gemm(R, need, x1, w, out, s.Mo, s.K, s.N, in_acc=R["inacc"] if s.fused_stats else None,
+        em_gemm(R, need, x1, w, out, s.Mo, s.K, s.N, in_acc=acc if s.fused_stats else None,
                 in_rows=s.So if s.fused_stats else 0)
     elif s.kind == "halo":
         B, (D, H, W) = s.B, s.din
         R.call("ctu_conv3_halo", BF16, x1, x2, w, out, None, B, D, H, W, s.C1, s.C2, s.N, 0, s.N, 0,
-               R["inacc"] if s.fused_stats else None, None, None, R["tnws"], 1 << 24, int(x1_b16))
+               acc if s.fused_stats else None, None, None, R["tnws"], 1 << 24, int(x1_b16))
     else:
         assert not x1_b16
         g = ops._geom(s.B, s.din, s.dout, s.C1, s.C2, s.N, s.k, s.stride, s.padding, 0)
@@ -245,7 +264,7 @@ def em_conv_fwd(R, need, spec: ConvSpec, x1, x2, w, out, *, x1_b16=0):
         if sk > 1:
             need.skws = max(need.skws, s.Mo * s.N)
         R.call("ctu_igemm_nt", BF16, x1, x2, w, out, g, _epi(s.N, splitk=sk, splitk_ws=R["skws"] if sk > 1 else None))
-    return s.fused_stats
+    return s.fused_stats and acc is not None
 
 
 def em_conv_dgrad(R, need, spec: ConvSpec, gy, wd, g1, g2, *, extra=None, extra2=None, gy_b16=0):
@@ -282,6 +301,12 @@ def em_conv_wgrad(R, need, spec: ConvSpec, gy, x1, x2, gw, *, stream, x1_b16=0, 
         R.call("ctu_igemm_tn", BF16, gy, s.N, x1, x2, gw, None, gq, R["tnws1"], 1 << 24, stream=stream)
         return
     N, K, taps = s.N, s.K, s.taps
+    if s.kind == "halo" and ops.WGRAD_PARTIALS:
+        # per-split partial panels summed AND transposed into the parameter layout by one reduce kernel: no panel, no permute
+        B, (D, H, W) = s.B, s.din
+        R.call("ctu_conv3_halo_wgrad_param", BF16, gy, x1, x2, gw, B, D, H, W, s.C1, s.C2, N, int(x1_b16), int(gy_b16),
+               R["wgws"], 256 * 54 * 1024 + 27 * 64 * 1024, stream=stream)
+        return
     need.panel = max(need.panel, taps * N * K)
     if s.kind == "halo":
         B, (D, H, W) = s.B, s.din
@@ -298,13 +323,18 @@ def em_conv_wgrad(R, need, spec: ConvSpec, gy, x1, x2, gw, *, stream, x1_b16=0, 
 # ---------------------------------------------------------------------------------------------------------------
 # shared run-time plumbing
 # ---------------------------------------------------------------------------------------------------------------
-WS_NAMES = ("inacc", "tnws", "skws")
+WS_NAMES = ("ia0", "ia1", "iadirty", "tnws", "skws")
 BWD_WS_NAMES = ("s0", "s1", "dirty0", "tnws", "skws", "tnws1", "panel", "wgws")
 
 
-def _fwd_ws_values(device, sid, need: _Need):
+def _fwd_ws_values(device, sid, need: _Need, n_norms: int, last_n: int):
+    """Slot values of WS_NAMES for one forward replay, and the accumulator bookkeeping of its n_norms norms."""
     w = _fws(device, sid)
-    return [w.inacc.data_ptr(), ops._tn_workspace(device).data_ptr(), ops._splitk_workspace(device, need.skws).data_ptr()]
+    vals = [w.acc[w.apar].data_ptr(), w.acc[1 - w.apar].data_ptr(), w.adirty, ops._tn_workspace(device).data_ptr(),
+            ops._splitk_workspace(device, need.skws).data_ptr()]
+    w.apar ^= n_norms & 1
+    w.adirty = last_n
+    return vals
 
 
 def _grad_targets(weights, needs):
@@ -447,21 +477,19 @@ class _BneckPlan:
         y1, a1, y2, a2, y3 = R["y1"], R["a1"], R["y2"], R["a2"], R["y3"]
         st = [R["st"] + 32768 * i for i in range(4)]
         need = self.need
-        f = em_conv_fwd(R, need, c1, R["x"], None, R["w1"], y1)
-        em_in_fwd(R, y1, st[0], a1, B, c1.So, P, fused=f, act=1, b16=self.a1_b16)
-        f = em_conv_fwd(R, need, c2, a1, None, R["w2"], y2, x1_b16=self.a1_b16)
-        em_in_fwd(R, y2, st[1], a2, B, c2.So, P, fused=f, act=1)
-        f3 = em_conv_fwd(R, need, c3, a2, None, R["w3"], y3)
-        # (the statistics of y3 wait in "inacc" only if nothing else needs it in between: finalize first)
-        R.call("ctu_in_finalize", B, c3.So, N4, R["inacc"], st[2]) if f3 else \
-            R.call("ctu_in_stats", BF16, y3, B, c3.So, N4, R["inacc"], st[2])
+        nf = _InFwd(R)
         res = R["x"]
-        if cd is not None:
-            yd = R["yd"]
-            f = em_conv_fwd(R, need, cd, R["x"], None, R["wd"], yd)
-            em_in_fwd(R, yd, st[3], R["rd"], B, cd.So, N4, fused=f, act=0)
+        if cd is not None:   # the shortcut branch first: its norm is done before conv3's sums need an accumulator
+            f = em_conv_fwd(R, need, cd, R["x"], None, R["wd"], R["yd"], acc=nf.acc())
+            nf.emit(R["yd"], st[3], R["rd"], B, cd.So, N4, fused=f, act=0)
             res = R["rd"]
-        R.call("ctu_in_apply", BF16, y3, st[2], res, R["out"], B, c3.So, N4, 1, 0, R["mask"])
+        f = em_conv_fwd(R, need, c1, R["x"], None, R["w1"], y1, acc=nf.acc())
+        nf.emit(y1, st[0], a1, B, c1.So, P, fused=f, act=1, b16=self.a1_b16)
+        f = em_conv_fwd(R, need, c2, a1, None, R["w2"], y2, x1_b16=self.a1_b16, acc=nf.acc())
+        nf.emit(y2, st[1], a2, B, c2.So, P, fused=f, act=1)
+        f = em_conv_fwd(R, need, c3, a2, None, R["w3"], y3, acc=nf.acc())
+        nf.emit(y3, st[2], R["out"], B, c3.So, N4, fused=f, residual=res, act=1, mask=R["mask"])
+        self.f_norms, self.f_last = nf.k, nf.prev
         self.fwd = R.finish()
 
     BWD_SLOTS = ("x", "gy", "gx", "w1d", "w2d", "w3d", "wdd", "gw1", "gw2", "gw3", "gwd") + BWD_WS_NAMES
@@ -529,8 +557,8 @@ class BottleneckFn(torch.autograd.Function):
         wdf = conv_weights(pl.cd, wd, dgrad=False)[0] if wd is not None else None
         sid = L.stream()
         vals = [x.data_ptr(), out.data_ptr(), rd.data_ptr() if rd is not None else 0, w1f.data_ptr(),
-                w2f.data_ptr(), w3f.data_ptr(), wdf.data_ptr() if wdf is not None else 0] + _fwd_ws_values(dev, sid, pl.need) + \
-               [t.data_ptr() for t in bufs]
+                w2f.data_ptr(), w3f.data_ptr(), wdf.data_ptr() if wdf is not None else 0] + \
+            _fwd_ws_values(dev, sid, pl.need, pl.f_norms, pl.f_last) + [t.data_ptr() for t in bufs]
         pl.fwd.run(vals, (sid,))
         ctx.pl = pl
         ctx.bufs = bufs
@@ -982,19 +1010,17 @@ class _ResBlockPlan:
         x2 = R["x2"] if self.C2 else None
         st = [R["st"] + 32768 * i for i in range(3)]
         need = self.need
-        f = em_conv_fwd(R, need, c1, R["x1"], x2, R["w1"], R["y1"])
-        em_in_fwd(R, R["y1"], st[0], R["a1"], B, S, N, fused=f, act=1, b16=self.a1_b16)
-        f = em_conv_fwd(R, need, c2, R["a1"], None, R["w2"], R["y2"], x1_b16=self.a1_b16)
-        if f:
-            R.call("ctu_in_finalize", B, S, N, R["inacc"], st[1])
-        else:
-            R.call("ctu_in_stats", BF16, R["y2"], B, S, N, R["inacc"], st[1])
+        nf = _InFwd(R)
         res = R["x1"]
-        if c3 is not None:
-            f = em_conv_fwd(R, need, c3, R["x1"], x2, R["w3"], R["y3"])
-            em_in_fwd(R, R["y3"], st[2], R["rd"], B, S, N, fused=f, act=0)
+        if c3 is not None:   # the shortcut branch first (see _BneckPlan.record_fwd)
+            f = em_conv_fwd(R, need, c3, R["x1"], x2, R["w3"], R["y3"], acc=nf.acc())
+            nf.emit(R["y3"], st[2], R["rd"], B, S, N, fused=f, act=0)
             res = R["rd"]
-        R.call("ctu_in_apply", BF16, R["y2"], st[1], res, R["out"], B, S, N, 1, 0, R["mask"])
+        f = em_conv_fwd(R, need, c1, R["x1"], x2, R["w1"], R["y1"], acc=nf.acc())
+        nf.emit(R["y1"], st[0], R["a1"], B, S, N, fused=f, act=1, b16=self.a1_b16)
+        f = em_conv_fwd(R, need, c2, R["a1"], None, R["w2"], R["y2"], x1_b16=self.a1_b16, acc=nf.acc())
+        nf.emit(R["y2"], st[1], R["out"], B, S, N, fused=f, residual=res, act=1, mask=R["mask"])
+        self.f_norms, self.f_last = nf.k, nf.prev
         self.fwd = R.finish()
 
     BWD_SLOTS = ("x1", "x2", "gy", "gx1", "gx2", "ext", "w1d", "w2d", "w3d", "gw1", "gw2", "gw3") + BWD_WS_NAMES
@@ -1063,7 +1089,7 @@ class ResBlockFn(torch.autograd.Function):
         sid = L.stream()
         vals = [x1.data_ptr(), x2.data_ptr() if x2 is not None else 0, out.data_ptr(), rd.data_ptr() if rd is not None else 0,
                 w1f.data_ptr(), w2f.data_ptr(), w3f.data_ptr() if w3f is not None else 0] + \
-            _fwd_ws_values(dev, sid, pl.need) + [t.data_ptr() for t in bufs]
+            _fwd_ws_values(dev, sid, pl.need, pl.f_norms, pl.f_last) + [t.data_ptr() for t in bufs]
         pl.fwd.run(vals, (sid,))
         ctx.pl, ctx.bufs, ctx.grad_stash = pl, bufs, grad_stash
         ctx.save_for_backward(x1, x2, w1, w2, w3)

@@ -169,6 +169,13 @@ int ctu_conv3_halo(ctu_dtype dtype, const void* x1, const void* x2, const void* 
 int ctu_conv3_halo_wgrad(ctu_dtype dtype, const void* dy, const void* x1, const void* x2, float* dw, int32_t B,
                          int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N, int32_t x1_layout,
                          int32_t dy_layout, float* ws, int64_t ws_floats, ctu_stream_t stream);
+/* The same with the result ADDED straight into the parameter's own layout dw_param[N][C1+C2][27] (nn.Conv3d weight,
+ * resnet.py:35-50): the per-split partial panels are summed and transposed by one reduce kernel - no [27][N][K] panel, no
+ * permute pass.  bf16 LDS-DMA kernel only; ws must hold splits x 27 x N x (C1+C2) floats (<= 256 x 54 x 1024 for every
+ * shape), else CTU_ERR_ARG. */
+int ctu_conv3_halo_wgrad_param(ctu_dtype dtype, const void* dy, const void* x1, const void* x2, float* dw_param, int32_t B,
+                               int32_t D, int32_t H, int32_t W, int32_t C1, int32_t C2, int32_t N, int32_t x1_layout,
+                               int32_t dy_layout, float* ws, int64_t ws_floats, ctu_stream_t stream);
 /* Pack fp32 weights W(n, c, tap) = src[n*sn + c*sc + tap*st] into MFMA-fragment order
  * dst[K/32][taps][2][ceil(N/32)][64 lanes][8] (zero padded), optionally with the tap order reversed (flip = 1). */
 int ctu_pack_frag(const float* src, void* dst, ctu_dtype dst_dtype, int32_t N, int32_t K, int32_t taps, int64_t sn,
@@ -215,6 +222,15 @@ int ctu_in_finalize(int32_t B, int64_t S, int32_t C, double* acc, float* stats, 
  * this byte instead of a 16-byte vector of y (twice). */
 int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, const void* residual, void* y, int32_t B,
                  int64_t S, int32_t C, int32_t act, int32_t y_layout, uint8_t* sign_mask, ctu_stream_t stream);
+/* ctu_in_apply with the finalize step folded in (launch lists: one launch per norm instead of two).  raw_acc (optional):
+ * UNSHIFTED fp64 sums (sum x, sum x^2) [B][C][2] from a producer's epilogue (ctu_conv3_halo / ctu_igemm_nt in_acc); (mean, rstd)
+ * are derived from them inside the kernel and WRITTEN to stats (the backward pass reads them there); with raw_acc == NULL
+ * stats is an input as in ctu_in_apply.  raw_acc is left as it is: clear_ws[0..clear_n) (optional, != raw_acc) names another
+ * accumulator that no launch still reads - the previous norm's - and is zeroed here, so two accumulators alternate
+ * without a memset or finalize launch. */
+int ctu_in_apply_acc(ctu_dtype dtype, const void* x, const double* raw_acc, float* stats, const void* residual, void* y,
+                     int32_t B, int64_t S, int32_t C, int32_t act, int32_t y_layout, uint8_t* sign_mask, double* clear_ws,
+                     int32_t clear_n, ctu_stream_t stream);
 /* backward: g = dy * act'(y) (y may be NULL when no residual was added: then sign(y) == sign(xhat) and the third
  * input stream is skipped; with sign_mask from ctu_in_apply, y is not read either); sums[b][c] = (sum g, sum g*xhat), fp64, zero on entry;
  * dx = rstd*(g - s1/S - xhat*s2/S); dres = g when dres != NULL.  ctu_in_bwd_apply also zeroes clear_ws[0..clear_n)
