@@ -94,11 +94,26 @@ class KernelTimer:
         return out
 
 
+def source_hash():
+    """Hash of what decides a kernel's HBM traffic: the HIP sources, the C ABI and this file.  tools/pmc_traffic.py stores it
+    with a PMC profile; a profile taken from other sources is not quoted."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, "hybrid-ctunet_amd")
+    for f in sorted(glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.h")) +
+                    [os.path.join(ROOT, "include", "ctunet_hip.h"), os.path.join(pkg, "ops.py"), os.path.join(pkg, "ops_fused.py")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(entry_point):
     """(bytes, source): HBM bytes per launch of the dominant entry point's kernels from the newest committed rocprofv3 PMC
     passes over this very command (profiles/r*_pmc_hbm_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate passes, per
-    the guide's gfx950 correction).  Counters cannot be read from inside the process, so this is the last profiled value
-    (the file name says of which round), not a live one; (None, None) when no file is present."""
+    the guide's gfx950 correction).  Counters cannot be read from inside the process, so this is the last profiled value,
+    not a live one: the file records the hash of the sources it was taken from (source_hash) and the commit; when the
+    kernels or the host path changed since, the figure is dropped (None) and the source field says so."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
     path = files[-1] if files else ""
@@ -106,13 +121,16 @@ def pmc_traffic(entry_point):
            "ctu_igemm_nt": "gemm_nt_dma_kernel", "ctu_igemm_tn": "gemm_tn_dma_kernel"}.get(entry_point)
     if key is None or not os.path.exists(path):
         return None, None
-    ks = json.load(open(path))["kernels"]
+    prof = json.load(open(path))
+    if prof.get("source_hash") != source_hash():
+        return None, f"{os.path.basename(path)} (commit {prof.get('commit', '?')}) is older than the sources: not quoted"
+    ks = prof["kernels"]
     n = b = 0.0
     for name, v in ks.items():
         if key in name:
             n += v["launches_per_step"]
             b += v["launches_per_step"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
-    return (round(b / n) if n else None), os.path.basename(path)
+    return (round(b / n) if n else None), f"{os.path.basename(path)} (commit {prof.get('commit', '?')})"
 
 
 def _cpu_model_name():
@@ -162,6 +180,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=32.0)
+    ap.add_argument("--payload", default="fp32", choices=["fp32", "bf16"],
+                    help="gradient exchange payload for N > 1: fp32 = one ncclAllReduce(ncclAvg) per bucket (torch's RCCL binding); "
+                         "bf16 = ctu_allreduce_bucket (cast -> all-to-all -> fp32 sum -> all-gather: half the bytes on every xGMI "
+                         "link, csrc/comm.hip) over a communicator bootstrapped from torch.distributed")
     ap.add_argument("--stage-graphs", action="store_true",
                     help="replay the launch-latency-bound stages (ResNet layer3/4, ViT trunk, first window stages) from HIP "
                          "graphs (graphs.graph_stages).  Off by default: measured 50.8 ms / step against 49.4 ms without - "
@@ -214,7 +236,12 @@ def main():
     flat = H.FlatParams(order)
     # static_unused: the parameters without a gradient in the first (warm-up) step never get one (seven ResBlock.conv3 that the
     # models build and never call); their buckets then go out during backward instead of behind it (train.DataParallel)
-    dp = H.DataParallel(model, flat=flat, bucket_mb=a.bucket_mb, static_unused=a.warmup > 0) if world > 1 else None
+    comm = None
+    if world > 1 and a.payload == "bf16":
+        from hybrid_ctunet_amd.comm import Communicator
+        comm = Communicator.from_torch()
+    dp = H.DataParallel(model, flat=flat, bucket_mb=a.bucket_mb, static_unused=a.warmup > 0, payload=a.payload,
+                        comm=comm) if world > 1 else None
     use_graph = world == 1 and a.graph and not a.serial
     # the optimizer updates a bucket of parameters as soon as its gradients are final (behind the bucket's all-reduce for N > 1):
     # same arithmetic as one update after backward(), queued under the rest of the backward pass (train.FusedAdamW)
@@ -226,7 +253,7 @@ def main():
     x, y = synthetic_batch(a.batch, seed=1000 + rank)
     x, y = x.to(dev), y.to(dev)
     use_bf16 = a.precision == "bf16"
-    from hybrid_ctunet_amd import ops as _ops
+    from hybrid_ctunet_amd import ops as _ops, ops_fused as _fused
 
     def set_serial(flag):
         """Serial = every kernel on one stream.  The timed region overlaps the two encoder branches and the weight-gradient
@@ -295,6 +322,31 @@ def main():
         elapsed = t.item()
     final_loss = loss.item()
 
+    # After the timed region, per rank: (1) host time to ENQUEUE one step into an empty queue (no back-pressure from a full
+    # HIP queue: the launch thread's own cost), (2) with N > 1 the time the compute stream stood waiting for the gradient
+    # exchange in DataParallel.finish() (event pair around that wait: communication the backward pass did not hide).
+    enq, exposed = [], []
+    for _ in range(3):
+        fence()
+        if dp is not None:
+            dp.exposed = []
+        h0 = time.perf_counter()
+        loss = step()
+        enq.append(1e3 * (time.perf_counter() - h0))
+        torch.cuda.synchronize()
+        if dp is not None and dp.exposed:
+            exposed.append(sum(e0.elapsed_time(e1) for e0, e1 in dp.exposed))
+    if dp is not None:
+        dp.exposed = None
+    host_ms = sorted(enq)[1]
+    exposed_ms = sorted(exposed)[len(exposed) // 2] if exposed else 0.0
+    per_rank = [[round(host_ms, 2), round(exposed_ms, 3)]]
+    if world > 1:
+        t = torch.tensor([host_ms, exposed_ms], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allr, t)
+        per_rank = [[round(v[0].item(), 2), round(v[1].item(), 3)] for v in allr]
+
     roofline = None
     step = eager_step
     if not a.no_roofline:
@@ -346,10 +398,15 @@ def main():
             "config": {"workload": f"{a.model} d101 pf8, per-GPU batch {a.batch} x 1x96x96x96, fwd + DiceCE "
                                    f"(deep supervision, on-device targets) + bwd + fused AdamW"
                                    + (" + RCCL bucketed grad all-reduce" if world > 1 else ""),
-                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "launch": graph_note, "optimizer": "per-bucket updates under backward" if opt_overlap else "one update after backward",
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "launch": graph_note, "host_path": "launch lists (ctu_plan_run)" if _fused.ENABLED else "per-op",
+                       **({"grad_payload": a.payload} if world > 1 else {}), "optimizer": "per-bucket updates under backward" if opt_overlap else "one update after backward",
                        **({"route": a.route} if a.route else {}),
                        "params_M": round(n_params / 1e6, 2),
                        "final_loss": round(final_loss, 5)},
+            "host_enqueue_ms_per_step": max(r[0] for r in per_rank),
+            "per_rank": {"host_enqueue_ms": [r[0] for r in per_rank], "exposed_comm_ms": [r[1] for r in per_rank],
+                         "note": "after the timed region, median of 3 steps: host time to enqueue one step into an empty queue; "
+                                 "time the compute stream waited for the gradient exchange in DataParallel.finish()"},
             "whole_path_tflops_per_gpu": round(whole_path, 2),
             "whole_path_frac_of_mfma_peak": round(whole_path / PEAK_BF16_TFLOPS, 4),
         }

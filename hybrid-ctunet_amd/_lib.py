@@ -93,6 +93,7 @@ _SIGS = {
     "ctu_comm_init": [C.c_char_p, _i32, _i32, _vp, C.POINTER(_vp)],
     "ctu_comm_destroy": [_vp],
     "ctu_allreduce_bucket": [_vp, _vp, _i64, _i32, _vp, _i64, _vp],
+    "ctu_allreduce_bucket_stage": [_i32, _i32, _vp, _i64, _vp, _i64, _vp],
     "ctu_plan_create": [C.POINTER(C.c_uint64), _i64, C.POINTER(C.c_uint64), _i64, _i32, _i32, C.POINTER(_vp)],
     "ctu_plan_run": [_vp, C.POINTER(C.c_uint64), _i32, C.POINTER(_vp), _i32],
     "ctu_plan_destroy": [_vp],
@@ -103,18 +104,23 @@ _lib = None
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/*.hip into csrc/libctunet_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(_HERE, "..", "include", "ctunet_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    """Compile csrc/*.hip into csrc/libctunet_hip.so for gfx950 (hipcc cross-compiles without a GPU).  `make` decides what is
+    stale (every object depends on all headers, the generated plan_dispatch.inc and include/ctunet_hip.h), so a library older
+    than any source is rebuilt; without hipcc (the GPU box never builds) an up-to-date library is accepted and a stale one
+    refused."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], capture_output=True, text=True)
+    fresh = subprocess.run(["make", "-C", CSRC, "-q", f"HIPCC={hipcc}"], capture_output=True, text=True).returncode == 0
+    if fresh and os.path.exists(LIB_PATH):
+        return LIB_PATH
     cmd = ["make", "-C", CSRC, "-j4", f"HIPCC={hipcc}"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout[-4000:], res.stderr[-4000:])
     if res.returncode != 0 or not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"building libctunet_hip.so failed (exit {res.returncode})")
+        raise RuntimeError(f"building libctunet_hip.so failed (exit {res.returncode}): the in-tree library is missing or older "
+                           "than its sources")
     return LIB_PATH
 
 

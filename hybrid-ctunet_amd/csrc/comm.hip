@@ -160,6 +160,26 @@ extern "C" int64_t ctu_allreduce_scratch_bytes(int32_t world, int64_t n) {
   return (2 * chunk * world + chunk) * 2;  // send/gather [world][chunk], recv [world][chunk], mean [chunk], bf16
 }
 
+// One LOCAL stage of the bf16 exchange for a rank of a `world`-rank job, without a communicator: 0 = cast (buf -> send
+// region of scratch), 1 = reduce (recv region -> mean region), 2 = expand (send region, holding the gathered means -> buf).
+// With the two collectives played by plain copies between the scratch buffers of several virtual ranks, one GPU checks the
+// chunking, the padding and the ragged tail of the dataflow for any world size (tests/test_dp_gpu.py).
+extern "C" int ctu_allreduce_bucket_stage(int32_t stage, int32_t world, float* buf, int64_t n, void* scratch,
+                                          int64_t scratch_bytes, ctu_stream_t stream_) {
+  CTU_REQUIRE(buf && n > 0 && world > 0 && stage >= 0 && stage <= 2, "ctu_allreduce_bucket_stage: bad arguments");
+  CTU_REQUIRE(scratch && scratch_bytes >= ctu_allreduce_scratch_bytes(world, n), "ctu_allreduce_bucket_stage: scratch too small");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int64_t chunk = ((n + world - 1) / world + 7) / 8 * 8;
+  const int64_t padded = chunk * world;
+  bf16* send = static_cast<bf16*>(scratch);
+  bf16* recv = send + padded;
+  bf16* mean = recv + padded;
+  if (stage == 0) bucket_cast_kernel<<<grid_for(padded / 8, 256, 2048), 256, 0, stream>>>(buf, send, n, padded);
+  else if (stage == 1) bucket_reduce_kernel<<<grid_for(chunk / 8, 256, 2048), 256, 0, stream>>>(recv, mean, chunk, world, 1.0f / world);
+  else bucket_expand_kernel<<<grid_for(padded / 8, 256, 2048), 256, 0, stream>>>(send, buf, n, padded);
+  return ctu_check_launch("ctu_allreduce_bucket_stage");
+}
+
 extern "C" int ctu_allreduce_bucket(void* handle, float* buf, int64_t n, int32_t payload, void* scratch, int64_t scratch_bytes,
                                     ctu_stream_t stream_) {
   Comm* c = static_cast<Comm*>(handle);

@@ -396,8 +396,13 @@ __global__ __launch_bounds__(256 * KG, (KG == 2 || R * (BM + BN) * BK * 2 > 76 *
               }
               if (want_res) {
                 const bf16x8 rv = resv[i * NR + t];
+                if (p.ep.act == 2) {   // GELU backward: `residual` holds the saved pre-activation, the product is dY.W
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] += (float)rv[e];
+                  for (int e = 0; e < 8; ++e) x[e] *= gelu_erf_grad((float)rv[e]);
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) x[e] += (float)rv[e];
+                }
               }
               bf16* dst;
               const size_t off = epilogue_offset(p.ep, out, m, n, dst);

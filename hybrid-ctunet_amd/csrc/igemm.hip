@@ -351,10 +351,14 @@ static int launch_nt(const void* a1, const void* a2, const void* w, void* out, c
   p.its_per_split = (n_it + p.splitk - 1) / p.splitk;
   p.splitk = (n_it + p.its_per_split - 1) / p.its_per_split;
   p.ws = ep->splitk_ws;
+  if (ep->act == 2 && (!ep->residual || p.splitk > 1 || ep->bias)) {
+    ctu_set_error("igemm_nt: act 2 (GELU backward) multiplies by GELU'(residual): needs residual, no bias, no split-K");
+    return CTU_ERR_ARG;
+  }
   if (NtDma<T>::launch(a1, a2, w, out, g, ep, p, stream)) {
     // plain bf16 GEMM on the LDS-DMA kernel (gemm_dma.hip); p.splitk holds the split it used
-  } else if (ep->w_kn || ep->in_acc || ep->pre_out) {
-    ctu_set_error("igemm_nt: w_kn / in_acc / pre_out need a plain bf16 GEMM with K %% 32 == 0 (see ctu_epilogue)");
+  } else if (ep->w_kn || ep->in_acc || ep->pre_out || ep->act == 2) {
+    ctu_set_error("igemm_nt: w_kn / in_acc / pre_out / act 2 need a plain bf16 GEMM with K %% 32 == 0 (see ctu_epilogue)");
     return CTU_ERR_ARG;
   } else if (g->N <= 64) {
     p.tiles_n = (g->N + 63) / 64;

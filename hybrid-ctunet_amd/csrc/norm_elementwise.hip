@@ -111,21 +111,30 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, 
   const int cg = (int)(i0 % ncg);
   float mean[8], rstd[8];
   if (raw) {
+    // one fp64 division and square root per CHANNEL and workgroup (thread t: channels t, t + 256, ...), handed round through
+    // LDS - every thread deriving its own eight channels cost 3 us per launch over 8 192 workgroups
+    // (dynamic LDS, 8 bytes per channel: a kilobyte at 128 channels still fits beside a pair of halo-convolution workgroups)
+    extern __shared__ float in_apply_lds[];
+    float* sm = in_apply_lds;
+    float* sr = in_apply_lds + C;
     const double inv_s = 1.0 / (double)S;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const size_t o = ((size_t)b * C + cg * 8 + e) * 2;
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const size_t o = ((size_t)b * C + c) * 2;
       const double m = raw[o] * inv_s;
       const double var = fmax(raw[o + 1] * inv_s - m * m, 0.0);
-      mean[e] = (float)m;
-      rstd[e] = (float)(1.0 / sqrt(var + (double)NORM_EPS));
-    }
-    if (blockIdx.x == 0 && threadIdx.x < ncg) {   // (grid.x * 256 is a multiple of ncg: thread t of block 0 holds column group t)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        stats[((size_t)b * C + cg * 8 + e) * 2] = mean[e];
-        stats[((size_t)b * C + cg * 8 + e) * 2 + 1] = rstd[e];
+      const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)NORM_EPS));
+      sm[c] = mf;
+      sr[c] = rf;
+      if (blockIdx.x == 0) {
+        stats[o] = mf;
+        stats[o + 1] = rf;
       }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      mean[e] = sm[cg * 8 + e];
+      rstd[e] = sr[cg * 8 + e];
     }
   } else {
     in_mean_rstd(stats, b, C, cg * 8, 0.f, mean, rstd);
@@ -388,10 +397,11 @@ static int in_apply_impl(ctu_dtype dtype, const void* x, const double* raw, floa
   const int64_t yb16 = y_layout == CTU_LAYOUT_B16 ? (int64_t)B * S : 0;
   const dim3 grid(in_stream_grid(S, C, B), B);
   hipStream_t s = (hipStream_t)stream;
+  const size_t lds = raw ? (size_t)2 * C * sizeof(float) : 0;
   CTU_DISPATCH(dtype,
-               hipLaunchKernelGGL(in_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, stats,
+               hipLaunchKernelGGL(in_apply_kernel<float>, grid, dim3(256), lds, s, (const float*)x, stats,
                                   (const float*)residual, (float*)y, S, C, act, yb16, sign_mask, raw, clear_ws, clear_n),
-               hipLaunchKernelGGL(in_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, stats,
+               hipLaunchKernelGGL(in_apply_kernel<bf16>, grid, dim3(256), lds, s, (const bf16*)x, stats,
                                   (const bf16*)residual, (bf16*)y, S, C, act, yb16, sign_mask, raw, clear_ws, clear_n));
   return ctu_check_launch("in_apply");
 }

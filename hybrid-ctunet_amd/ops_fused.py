@@ -28,6 +28,15 @@ from ._plan import Recorder, Ref
 
 BF16 = L.CTU_BF16
 ENABLED = not os.environ.get("CTU_NO_PLANS")
+# A/B switches for measurements (CTU_OPT="gelu2=0,acc=0": comma-separated name=0/1; read once at import, part of every plan key)
+OPT = {"gelu2": 1,    # GELU backward inside the data-gradient GEMM of the Linear behind it (ctu_epilogue.act = 2)
+       "acc": 1,      # InstanceNorm finalize folded into the apply kernel (ctu_in_apply_acc)
+       "wparam": 1}   # halo weight gradients reduced straight into the parameter layout (ctu_conv3_halo_wgrad_param)
+for _kv in filter(None, os.environ.get("CTU_OPT", "").split(",")):
+    _k, _, _v = _kv.partition("=")
+    if _k not in OPT:
+        raise ValueError(f"CTU_OPT: unknown switch {_k!r}")
+    OPT[_k] = int(_v or 1)
 _cache: Dict[tuple, object] = {}
 
 _EPI_OFF = {n: getattr(Epilogue, n).offset for n in ("bias", "residual", "out2", "splitk_ws", "in_acc", "pre_out")}
@@ -44,7 +53,7 @@ def usable(x: torch.Tensor) -> bool:
 
 
 def _flags():
-    return (ops.B16_LAYOUT, ops.WGRAD_PARTIALS, ops.WGRAD_STREAM)
+    return (ops.B16_LAYOUT, ops.WGRAD_PARTIALS, ops.WGRAD_STREAM, tuple(OPT.values()))
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -145,7 +154,7 @@ class _Need:
 def em_gemm(R: Recorder, need: _Need, x, w, out, M, K, N, *, bias=None, residual=None, act=0, w_kn=0, in_acc=None,
             in_rows=0, pre_out=None, stream=0):
     """ops._plain_gemm: out[M,N] = act(x[M,K] @ w^T + bias) + residual."""
-    sk = 1 if (in_acc is not None or pre_out is not None) else ops._splitk_for(M, N, K, dma=K % 32 == 0)
+    sk = 1 if (in_acc is not None or pre_out is not None or act == 2) else ops._splitk_for(M, N, K, dma=K % 32 == 0)
     if sk > 1:
         need.skws = max(need.skws, M * N)
     e = _epi(N, bias=bias, residual=residual, act=act, splitk_ws=R["skws"] if sk > 1 else None, splitk=sk, w_kn=w_kn,
@@ -170,6 +179,9 @@ class _InFwd:
         clear_n = R.ival("iadirty") if self.k == 0 else self.prev
         if not fused:
             R.call("ctu_in_stats", BF16, y, B, S, C, acc, stats)     # (leaves its accumulator zeroed)
+        elif not OPT["acc"]:
+            R.call("ctu_in_finalize", B, S, C, acc, stats)           # (A/B: the separate finalize launch; zeroes acc)
+            fused = False
         R.call("ctu_in_apply_acc", BF16, y, acc if fused else None, stats, residual, out, B, S, C, int(act), int(b16), mask,
                other, clear_n)
         self.k += 1
@@ -301,7 +313,7 @@ def em_conv_wgrad(R, need, spec: ConvSpec, gy, x1, x2, gw, *, stream, x1_b16=0, 
         R.call("ctu_igemm_tn", BF16, gy, s.N, x1, x2, gw, None, gq, R["tnws1"], 1 << 24, stream=stream)
         return
     N, K, taps = s.N, s.K, s.taps
-    if s.kind == "halo" and ops.WGRAD_PARTIALS:
+    if s.kind == "halo" and ops.WGRAD_PARTIALS and OPT["wparam"]:
         # per-split partial panels summed AND transposed into the parameter layout by one reduce kernel: no panel, no permute
         B, (D, H, W) = s.B, s.din
         R.call("ctu_conv3_halo_wgrad_param", BF16, gy, x1, x2, gw, B, D, H, W, s.C1, s.C2, N, int(x1_b16), int(gy_b16),
@@ -707,7 +719,8 @@ class FFRes(_Layer):
         M, D, Hd = self.M, self.dim, self.hidden
         for nm, nb in (("h", M * D * 2), ("mr", M * 8), ("pre", M * Hd * 2), ("u", M * Hd * 2), ("y", M * D * 2)):
             F.add(self.n(nm), nb)
-        for nm, nb in (("gu", M * Hd * 2), ("gpre", M * Hd * 2), ("gh", M * D * 2), ("gx", M * D * 2)):
+        fused_gelu = D % 64 == 0 and Hd % 8 == 0 and OPT["gelu2"]
+        for nm, nb in ((() if fused_gelu else (("gu", M * Hd * 2),)) + (("gpre", M * Hd * 2), ("gh", M * D * 2), ("gx", M * D * 2))):
             G.add(self.n(nm), nb)
 
     def fwd(self, R, need, x):
@@ -719,9 +732,13 @@ class FFRes(_Layer):
 
     def bwd(self, R, need, x, gy, wg):
         n, M, D, Hd = self.n, self.M, self.dim, self.hidden
-        _lin_dgrad(R, need, gy, R[n("w2")], self.t(R, "w2"), R[n("gu")], M, D, Hd)
+        if D % 64 == 0 and Hd % 8 == 0 and OPT["gelu2"]:
+            # dY.W2 leaves the GEMM already multiplied by GELU'(pre): no [M, hidden] gradient tensor written and re-read
+            em_gemm(R, need, gy, R[n("w2")], R[n("gpre")], M, D, Hd, w_kn=1, act=2, residual=R[n("pre")])
+        else:
+            _lin_dgrad(R, need, gy, R[n("w2")], self.t(R, "w2"), R[n("gu")], M, D, Hd)
+            R.call("ctu_gelu_bwd", BF16, R[n("gu")], R[n("pre")], R[n("gpre")], M * Hd)
         _lin_wgrad(R, gy, R[n("u")], R[n("w2") + ".g"], R[n("b2") + ".g"], M, D, Hd, wg())
-        R.call("ctu_gelu_bwd", BF16, R[n("gu")], R[n("pre")], R[n("gpre")], M * Hd)
         _lin_dgrad(R, need, R[n("gpre")], R[n("w1")], self.t(R, "w1"), R[n("gh")], M, Hd, D)
         _lin_wgrad(R, R[n("gpre")], R[n("h")], R[n("w1") + ".g"], R[n("b1") + ".g"], M, Hd, D, wg())
         R.call("ctu_layernorm_bwd_add", BF16, R[n("gh")], x, R[n("g")], R[n("mr")], gy, R[n("gx")], R[n("g") + ".g"],

@@ -589,6 +589,7 @@ class DataParallel(nn.Module):
         if optimizer is not None:
             self.attach_optimizer(optimizer)
         self._home = torch.cuda.current_stream() if self._is_cuda else None
+        self.exposed = None   # a list: finish() appends an event pair around the compute stream's wait for the exchange
         f.listeners.append(self._on_ready)  # fires for autograd-accumulated and for directly accumulated gradients
         if broadcast and self.world > 1:
             dist.broadcast(f.flat, src=0, group=self.pg)  # DDP ctor semantics: rank 0's parameters win
@@ -692,7 +693,15 @@ class DataParallel(nn.Module):
             w.wait()
         self._works = []
         if self._is_cuda and self.world > 1:
-            torch.cuda.current_stream().wait_stream(self._side)
+            cur = torch.cuda.current_stream()
+            if self.exposed is not None:   # measurement: how long the compute stream stands waiting for the exchange
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self._side)
+                e1.record(cur)
+                self.exposed.append((e0, e1))
+            else:
+                cur.wait_stream(self._side)
         if self._static_unused and self._unused is None:
             self._unused = {i for i, s in enumerate(self._seen) if not s}
         unused = self._unused or ()

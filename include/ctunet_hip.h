@@ -79,7 +79,10 @@ typedef struct ctu_epilogue {
   const float* bias;    /* [N] fp32 or NULL                                  */
   const void* residual; /* [M][ldc] same dtype as out, added after act, or NULL; with a split output (n_split > 0) it is
                          * added to the columns that go to `out` only */
-  int32_t act;          /* 0 none, 1 exact-erf GELU                           */
+  int32_t act;          /* 0 none, 1 exact-erf GELU, 2 GELU backward: out = (a.w) * GELU'(residual) - `residual` holds the
+                         * pre-activation the forward pass saved (pre_out) and is NOT added; plain bf16 LDS-DMA GEMM, no
+                         * bias, no split-K: the data gradient of the Linear behind a GELU (vit.py:37-39,
+                         * hybrid_CTUNet.py:519-522) leaves the GEMM already multiplied, no elementwise pass in between */
   int32_t ldc;          /* leading dimension (elements) of out                */
   void* out2;           /* second destination for columns >= n_split, or NULL  */
   int32_t n_split;      /* 0 = unused; multiple of 8                           */
@@ -406,6 +409,12 @@ int ctu_plan_create(const uint64_t* words, int64_t nwords, const uint64_t* patch
                     int32_t nslots, void** handle);
 int ctu_plan_run(void* handle, const uint64_t* slots, int32_t nslots, void* const* streams, int32_t nstreams);
 int ctu_plan_destroy(void* handle);
+
+/* Verification hook: one local stage of the CTU_BF16 exchange as rank-independent kernels (0 cast, 1 reduce, 2 expand) on
+ * the scratch layout of ctu_allreduce_bucket - send [world][chunk] | recv [world][chunk] | mean [chunk], bf16, chunk =
+ * ceil(n / world) rounded up to 8 - so that a test can play the two collectives with copies on one GPU. */
+int ctu_allreduce_bucket_stage(int32_t stage, int32_t world, float* buf, int64_t n, void* scratch, int64_t scratch_bytes,
+                               ctu_stream_t stream);
 
 /* fp32 <-> dtype casts and fills */
 int ctu_cast(const void* src, ctu_dtype src_dtype, void* dst, ctu_dtype dst_dtype, int64_t n, ctu_stream_t stream);

@@ -190,3 +190,43 @@ def test_shared_weight_gradient_sink_reports_after_the_last_use():
     assert len(reports) >= 1
     for r in reports:
         assert torch.allclose(r[:4096].view(64, 64), wr.grad, rtol=2e-3, atol=2e-3 * wr.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_bf16_bucket_dataflow_with_virtual_ranks(world):
+    """The bf16 payload of ctu_allreduce_bucket - cast -> all-to-all -> fp32 sum x 1/world -> all-gather -> expand - at world
+    sizes the one-GPU box cannot run over RCCL: the three kernels are the real ones (ctu_allreduce_bucket_stage), the two
+    collectives are played by copies between the scratch buffers of `world` virtual ranks.  Checks chunking, the padding to
+    8 elements, the ragged tail, and that every rank - the chunk's owner included - ends with the same bf16-rounded means."""
+    from hybrid_ctunet_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(world)
+    for n in (1000003, 8 * 4096, 13):
+        xs = [torch.randn(n, generator=g).cuda() for _ in range(world)]
+        ref = torch.zeros(n, device="cuda")
+        for x in xs:
+            ref = ref + x.to(torch.bfloat16).float()          # the kernel's order: rank 0 first, fp32 accumulate
+        ref = (ref * torch.tensor(1.0 / world, dtype=torch.float32, device="cuda")).to(torch.bfloat16).float()
+        nbytes = L.ctu_allreduce_scratch_bytes(world, n)
+        chunk = ((n + world - 1) // world + 7) // 8 * 8
+        scr = [torch.empty(nbytes // 2, dtype=torch.bfloat16, device="cuda") for _ in range(world)]
+        bufs = [x.clone() for x in xs]
+        st = _lib.stream()
+        for r in range(world):
+            _lib.call("ctu_allreduce_bucket_stage", 0, world, bufs[r].data_ptr(), n, scr[r].data_ptr(), nbytes, st)
+        send = [s[:world * chunk].view(world, chunk) for s in scr]
+        recv = [s[world * chunk:2 * world * chunk].view(world, chunk) for s in scr]
+        mean = [s[2 * world * chunk:2 * world * chunk + chunk] for s in scr]
+        for r in range(world):                                  # all-to-all: rank r receives chunk r of every rank
+            for w in range(world):
+                recv[r][w].copy_(send[w][r])
+        for r in range(world):
+            _lib.call("ctu_allreduce_bucket_stage", 1, world, bufs[r].data_ptr(), n, scr[r].data_ptr(), nbytes, st)
+        for r in range(world):                                  # all-gather of the mean chunks into the send region
+            for w in range(world):
+                send[r][w].copy_(mean[w])
+        for r in range(world):
+            _lib.call("ctu_allreduce_bucket_stage", 2, world, bufs[r].data_ptr(), n, scr[r].data_ptr(), nbytes, st)
+        torch.cuda.synchronize()
+        for r in range(world):
+            assert torch.equal(bufs[r], ref), (world, n, r)

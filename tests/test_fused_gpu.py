@@ -55,7 +55,7 @@ def _compare(block, xs_list, direct):
             for i, (a, b) in enumerate(zip(got[2], ref[2])):
                 assert (a is None) == (b is None)
                 if a is not None:
-                    _close(a, b, f"dw{i}[{rep}]", tol=5e-3, same=0.0)   # (fp32 atomics: the summation order is not fixed)
+                    _close(a, b, f"dw{i}[{rep}]", tol=1.5e-2, same=0.0)   # (fp32 atomics: the summation order is not fixed; bf16 operands)
     finally:
         if flat is not None:
             flat.release()

@@ -5,7 +5,12 @@ import collections
 import csv
 import glob
 import json
+import os
+import subprocess
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_hash  # noqa: E402  (a profile is quoted by bench.py only while the sources it came from are current)
 
 
 def load(d):
@@ -33,7 +38,11 @@ rows.sort(reverse=True)
 print(f"per step: fetch {tf / steps / 1e9:.1f} GB, write {tw / steps / 1e9:.1f} GB")
 for t, k, n, fb, wb in rows[:14]:
     print(f"{k:62s} x{n / steps:6.1f}/step  fetch {fb / n / 1e6:8.1f} MB  write {wb / n / 1e6:8.1f} MB per launch  {t / steps / 1e9:6.2f} GB/step")
-json.dump({"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over python bench.py --serial --steps 2 "
+try:
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "?"
+except OSError:
+    commit = "?"
+json.dump({"source_hash": source_hash(), "commit": commit, "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over python bench.py --serial --steps 2 "
                    "--warmup 1 (single stream: a launch's counters are that kernel's alone); FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md section HBM); bytes per launch "
                    "averaged over the launches of a step",
            "per_step_GB": {"fetch": tf / steps / 1e9, "write": tw / steps / 1e9},
