@@ -335,11 +335,24 @@ def test_whole_model_bf16_against_reference_under_autocast(H, golden_dir, name):
     print(f"  gradient norms: median err {np.median(mine):.3e} / {np.median(ref):.3e}   max {max(mine):.3e} / {max(ref):.3e}")
     for j in np.argsort(mine)[-3:][::-1]:
         print(f"    largest: {names[j]:60s} {mine[j]:.3e} / {ref[j]:.3e}")
-    # the maximum over ~300 tensors is the noisiest statistic here: the step is not run-to-run deterministic (fp32 / fp64 atomics
-    # of kernels co-running on several streams) and the network amplifies a rounding difference ~1e4 times - the same build gave
-    # 5.3e-2 and 7.7e-2 for cunet101 in two consecutive runs, the reference under autocast 5.1e-2.  A wrong gradient shows as O(1).
-    if np.median(mine) > max(5e-3, 1.5 * np.median(ref)) or max(mine) > max(1e-1, 2.0 * max(ref)):
-        fails.append(("gradnorm", float(np.median(mine)), float(np.median(ref)), max(mine), max(ref)))
+    # The maximum over ~300 tensors is the noisiest statistic here, and it has a name: in three consecutive runs of one build
+    # (gpurun_out/r3_19, round 3) the three largest were always 1x1x1 convolution weights of convnet.layer1 -
+    # layer1.1.conv3, layer1.4.conv1, layer1.0.conv1 - at 4.2e-2 ... 8.0e-2 (the reference under autocast: 2.4e-2, 1.4e-2,
+    # 4e-3 on the same tensors, 5.1e-2 at its own worst).  Why these: a convolution followed by InstanceNorm leaves the loss
+    # invariant to the scale of each output channel's weight row, so the true gradient is orthogonal to W and its norm is the
+    # small residual of 442 368 x 2 cancelling bf16 outer products per entry (layer1 runs at 48 x 48 x 96, the longest
+    # reduction of all 1x1x1 layers); what is compared is that residual.  Why run-dependent: the InstanceNorm statistics
+    # upstream are summed with fp64 atomics in arrival order (an ulp of (mean, rstd) flips bf16 roundings of every activation
+    # behind it) and the weight gradient itself is a row-split TN GEMM whose partial panels meet in fp32 atomics / a two-stage
+    # sum - each run draws a new sample of the same rounding noise, amplified ~1e4 times by the norm stack.  A wrong gradient
+    # shows as O(1).  Gates: that family 1e-1 (or 2x the reference's own worst), every other tensor 7.5e-2.
+    noisy = [n.startswith("convnet.layer1.") and (".conv1." in n or ".conv3." in n or ".downsample." in n) for n in names]
+    worst_noisy = max([e for e, f in zip(mine, noisy) if f], default=0.0)
+    worst_rest = max([e for e, f in zip(mine, noisy) if not f], default=0.0)
+    print(f"    worst layer1 1x1x1 weight {worst_noisy:.3e}, worst other tensor {worst_rest:.3e}")
+    if (np.median(mine) > max(5e-3, 1.5 * np.median(ref)) or worst_noisy > max(1e-1, 2.0 * max(ref))
+            or worst_rest > max(7.5e-2, 2.0 * max(ref))):
+        fails.append(("gradnorm", float(np.median(mine)), float(np.median(ref)), worst_noisy, worst_rest, max(ref)))
     for j in range(8):
         k = str(z[f"grad/sample{j}/key"])
         got = pr[k].grad.flatten()[torch.from_numpy(z[f"grad/sample{j}/idx"]).cuda()].cpu().numpy()
