@@ -32,7 +32,10 @@ for _ in range(n):
 t1 = time.time()
 torch.cuda.synchronize()
 t2 = time.time()
-print(f"host enqueue {1e3 * (t1 - t0) / n:.1f} ms/step, device-complete {1e3 * (t2 - t0) / n:.1f} ms/step")
+# (with a launch thread faster than the device this first figure is NOT the host's cost: the HIP queues fill up and the launch
+#  calls block until the device drains them - the empty-queue figures below are what the host itself needs)
+print(f"back-to-back steps: loop returns after {1e3 * (t1 - t0) / n:.1f} ms/step (queue back-pressure included), "
+      f"device-complete {1e3 * (t2 - t0) / n:.1f} ms/step")
 # one step enqueued into an EMPTY queue, forward and backward separately: host time without back-pressure
 for _ in range(3):
     torch.cuda.synchronize()
