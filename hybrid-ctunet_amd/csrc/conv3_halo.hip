@@ -635,14 +635,17 @@ template <> struct HaloDma<bf16> {
     }
     const bool long_stages = (ctu_option_route() & CTU_ROUTE_HALO_TPS9) != 0;
     const bool alone = (ctu_option_route() & CTU_ROUTE_HALO_GATHER_WAVE0) != 0;  // previous rule: wave 0 gathers the halo alone
-    if (NT == 4 && alone) hipLaunchKernelGGL((conv3_halo_dma_kernel<4, 3, 3, false, 0>), grid, dim3(256), 0, s, q);
-    else if (NT == 4) hipLaunchKernelGGL(conv3_halo_dma_kernel<4>, grid, dim3(256), 0, s, q);
-    else if (NT == 2 && long_stages) hipLaunchKernelGGL((conv3_halo_dma_kernel<2, 2, 9, false, 0>), grid, dim3(256), 0, s, q);
-    else if (NT == 2 && alone) hipLaunchKernelGGL((conv3_halo_dma_kernel<2, 2, 3, false, 0>), grid, dim3(256), 0, s, q);
-    else if (NT == 2) hipLaunchKernelGGL(conv3_halo_dma_kernel<2>, grid, dim3(256), 0, s, q);
-    else if (long_stages) hipLaunchKernelGGL((conv3_halo_dma_kernel<1, 2, 9, false, 0>), grid, dim3(256), 0, s, q);
-    else if (alone) hipLaunchKernelGGL((conv3_halo_dma_kernel<1, 2, 3, false, 0>), grid, dim3(256), 0, s, q);
-    else hipLaunchKernelGGL(conv3_halo_dma_kernel<1>, grid, dim3(256), 0, s, q);
+    // CTU_ROUTE_HALO_THIN: a few KiB of unused dynamic LDS push the third (NT <= 2) / second (NT = 4) resident workgroup
+    // off the CU - its registers, wave slots and LDS are then free for kernels of other streams
+    const size_t thin = (ctu_option_route() & CTU_ROUTE_HALO_THIN) ? (NT == 4 ? 12 * 1024 : 4 * 1024) : 0;
+    if (NT == 4 && alone) hipLaunchKernelGGL((conv3_halo_dma_kernel<4, 3, 3, false, 0>), grid, dim3(256), thin, s, q);
+    else if (NT == 4) hipLaunchKernelGGL(conv3_halo_dma_kernel<4>, grid, dim3(256), thin, s, q);
+    else if (NT == 2 && long_stages) hipLaunchKernelGGL((conv3_halo_dma_kernel<2, 2, 9, false, 0>), grid, dim3(256), thin, s, q);
+    else if (NT == 2 && alone) hipLaunchKernelGGL((conv3_halo_dma_kernel<2, 2, 3, false, 0>), grid, dim3(256), thin, s, q);
+    else if (NT == 2) hipLaunchKernelGGL(conv3_halo_dma_kernel<2>, grid, dim3(256), thin, s, q);
+    else if (long_stages) hipLaunchKernelGGL((conv3_halo_dma_kernel<1, 2, 9, false, 0>), grid, dim3(256), thin, s, q);
+    else if (alone) hipLaunchKernelGGL((conv3_halo_dma_kernel<1, 2, 3, false, 0>), grid, dim3(256), thin, s, q);
+    else hipLaunchKernelGGL(conv3_halo_dma_kernel<1>, grid, dim3(256), thin, s, q);
     if (ksplit > 1) {
       const int64_t S = (int64_t)p.D * p.H * p.W;
       int64_t chunks = 1024 / p.B;

@@ -654,8 +654,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_stream_kernel(const GemmNtArgs
           }
           if (res) {
             const bf16x8 rv = resv[i][j][q];
+            if (p.ep.act == 2) {   // GELU backward: `residual` holds the saved pre-activation (ctu_epilogue.act)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] += (float)rv[e];
+              for (int e = 0; e < 8; ++e) x[e] *= gelu_erf_grad((float)rv[e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] += (float)rv[e];
+            }
           }
           // row r, 16-B slot 4 j + 2 q + h of the 128-B row, slot ^ (row & 7): conflict-free for the 8-lane write groups
           // (8 rows, one slot) and for the 16-lane read groups below (2 rows x 8 slots)
@@ -690,7 +695,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_stream_kernel(const GemmNtArgs
 static bool stream_ok(const GemmNtArgs& p) {
   const ctu_epilogue& e = p.ep;
   return (p.K == 32 || p.K == 64 || p.K == 128) && p.a2 == nullptr && p.C1 == p.K && p.N % 128 == 0 && p.M % 128 == 0 &&
-         p.M >= 128 * 256 && p.splitk <= 1 && !e.bias && e.act == 0 && !e.pre_out && !e.scatter && e.n_split <= 0 &&
+         p.M >= 128 * 256 && p.splitk <= 1 && !e.bias && (e.act == 0 || (e.act == 2 && e.residual)) && !e.pre_out &&
+         !e.scatter && e.n_split <= 0 &&
          (!p.in_acc || (p.in_rows % 128 == 0 && !e.residual)) && !(ctu_option_route() & CTU_ROUTE_NT_NO_STREAM);
 }
 static void launch_stream(const GemmNtArgs& p, hipStream_t stream) {

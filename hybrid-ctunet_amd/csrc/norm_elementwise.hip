@@ -980,12 +980,84 @@ __global__ __launch_bounds__(256) void pixel_shuffle_kernel(const T* __restrict_
     }
   }
 }
+// The same through LDS: a workgroup owns VOX consecutive input voxels.  Forward: their rows [c * P] arrive coalesced (16 B per
+// lane), each output vector gathers its 8 channels cc .. cc + 7 of one sub-position from LDS (stride P elements) and leaves
+// as a 16-byte store - every byte of the big tensor is read once (the per-output-element kernel above touches each 32-byte
+// sector of a row from P / 2 different waves: 1.2 TB/s at 442 k voxels x 128 channels).  Inverse: the other way round.
+template <bool INV>
+__global__ __launch_bounds__(256) void pixel_shuffle_lds_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const int B,
+                                                                const int D, const int H, const int W, const int c,
+                                                                const int p1, const int p2, const int p3, const int VOX) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ps_lds[];
+  bf16* tile = reinterpret_cast<bf16*>(ps_lds);   // [VOX][c * P]
+  const int P = p1 * p2 * p3;
+  const int CB = c * P;
+  const int ncg = c >> 3;
+  const int64_t nvox = (int64_t)B * D * H * W;
+  const int64_t v0 = (int64_t)blockIdx.x * VOX;
+  const int nv = (int)min((int64_t)VOX, nvox - v0);
+  const bf16* big_in = x + v0 * CB;   // (forward: the big tensor is the input)
+  bf16* big_out = y + v0 * CB;        // (inverse: the big tensor is the output)
+  const int vec_rows = CB >> 3;       // 16-byte vectors per big row
+  if (!INV) {
+    for (int i = threadIdx.x; i < nv * vec_rows; i += 256)
+      *reinterpret_cast<bf16x8*>(tile + (size_t)i * 8) = *reinterpret_cast<const bf16x8*>(big_in + (size_t)i * 8);
+    __syncthreads();
+  }
+  // small-layout vectors of this workgroup: (voxel, sub-position, channel group)
+  const int per_vox = P * ncg;
+  for (int i = threadIdx.x; i < nv * per_vox; i += 256) {
+    const int cg = i % ncg;
+    const int sub = (i / ncg) % P;
+    const int lv = i / per_vox;
+    const int64_t v = v0 + lv;
+    const int w = (int)(v % W);
+    const int h = (int)((v / W) % H);
+    const int d = (int)((v / ((int64_t)W * H)) % D);
+    const int b = (int)(v / ((int64_t)W * H * D));
+    const int i3 = sub % p3, i2 = (sub / p3) % p2, i1 = sub / (p3 * p2);
+    const size_t small = (((((size_t)b * D * p1 + d * p1 + i1) * (H * p2) + h * p2 + i2) * (size_t)(W * p3) + w * p3 + i3) * c) +
+                         (size_t)cg * 8;
+    bf16* t = tile + (size_t)lv * CB + (size_t)(cg * 8) * P + sub;
+    if (!INV) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = t[e * P];
+      *reinterpret_cast<bf16x8*>(y + small) = o;
+    } else {
+      const bf16x8 o = *reinterpret_cast<const bf16x8*>(x + small);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e * P] = o[e];
+    }
+  }
+  if (INV) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < nv * vec_rows; i += 256)
+      *reinterpret_cast<bf16x8*>(big_out + (size_t)i * 8) = *reinterpret_cast<const bf16x8*>(tile + (size_t)i * 8);
+  }
+}
+
 extern "C" int ctu_pixel_shuffle(ctu_dtype dtype, const void* x, void* y, int32_t B, int32_t D, int32_t H, int32_t W,
                                  int32_t c, int32_t p1, int32_t p2, int32_t p3, int32_t inverse, ctu_stream_t stream) {
   CTU_REQUIRE(x && y && B > 0 && D > 0 && H > 0 && W > 0 && c > 0 && c % 8 == 0 && p1 > 0 && p2 > 0 && p3 > 0,
               "pixel_shuffle: bad args (c must be a multiple of 8)");
-  const unsigned grid = grid_for((int64_t)B * D * H * W * p1 * p2 * p3 * (c / 8), 256);
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == CTU_BF16) {
+    const int CB = c * p1 * p2 * p3;
+    int VOX = 16384 / (CB * 2);   // 16 KiB of LDS per workgroup
+    if (VOX > 64) VOX = 64;
+    if (VOX >= 1) {
+      const int64_t nvox = (int64_t)B * D * H * W;
+      const dim3 g((unsigned)((nvox + VOX - 1) / VOX));
+      const size_t lds = (size_t)VOX * CB * 2;
+      if (inverse)
+        hipLaunchKernelGGL(pixel_shuffle_lds_kernel<true>, g, dim3(256), lds, s, (const bf16*)x, (bf16*)y, B, D, H, W, c, p1, p2, p3, VOX);
+      else
+        hipLaunchKernelGGL(pixel_shuffle_lds_kernel<false>, g, dim3(256), lds, s, (const bf16*)x, (bf16*)y, B, D, H, W, c, p1, p2, p3, VOX);
+      return ctu_check_launch("pixel_shuffle");
+    }
+  }
+  const unsigned grid = grid_for((int64_t)B * D * H * W * p1 * p2 * p3 * (c / 8), 256);
 #define PS_LAUNCH(T, INV) \
   hipLaunchKernelGGL((pixel_shuffle_kernel<T, INV>), dim3(grid), dim3(256), 0, s, (const T*)x, (T*)y, B, D, H, W, c, p1, p2, p3)
   if (inverse) { CTU_DISPATCH(dtype, PS_LAUNCH(float, true), PS_LAUNCH(bf16, true)); }

@@ -410,7 +410,7 @@ def test_pwa(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("f,c", [((2, 2, 2), 8), ((2, 2, 1), 16)])
+@pytest.mark.parametrize("f,c", [((2, 2, 2), 8), ((2, 2, 1), 16), ((2, 2, 2), 32), ((2, 2, 2), 96)])
 def test_pixel_shuffle_and_patchify(ops, dtype, f, c):
     from oracle import ctunet_oracle as O
     B, D, H, W = 2, 3, 4, 5
