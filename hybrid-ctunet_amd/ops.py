@@ -83,12 +83,50 @@ class _WgradSide:
                     t.record_stream(ws)              # freed by the caller's scope while the side stream may still read it
             self._cm = torch.cuda.stream(ws)
             self._cm.__enter__()
+            ensure_join_after_backward()
         return self
 
     def __exit__(self, *exc):
         if self.on:
             self._cm.__exit__(*exc)
         return False
+
+
+_join_queued = False
+
+
+_stash_watch = []   # slots a GradStash parked a gradient in during the backward pass that is running
+
+
+def _join_after_backward():
+    global _join_queued
+    _join_queued = False
+    join_side_streams()
+    lost = [s for s in _stash_watch if _parked(s)]
+    _stash_watch.clear()
+    if lost:
+        # the consumer the stash relies on (the layer whose data-gradient kernel adds the parked gradient in its epilogue) did
+        # not run in this backward pass - e.g. a loss over a deep-supervision head alone: plain autograd would have propagated
+        # that gradient, so dropping it silently would be wrong
+        for s in lost:
+            s.clear()
+        raise RuntimeError(f"{len(lost)} gradient(s) were parked by ops.GradStash but their consuming layer never ran in this "
+                           "backward pass (backpropagating through one head of a shared tensor only?); run such a backward with "
+                           "ops.STASH_SHORTCUT_CONV = False / without the model's gradient stashes")
+
+
+def ensure_join_after_backward():
+    """Called from a backward node that queued work on a companion stream: when the whole backward pass has been enqueued, the
+    stream backward() was called from waits for every side stream - so that whatever reads .grad next on that stream
+    (clip_grad_norm_, GradScaler.unscale_, a torch optimizer over FlatParams views, a test's .cpu()) is ordered behind the
+    weight-gradient kernels without knowing about them.  One engine callback per backward pass."""
+    global _join_queued
+    if not _join_queued:
+        _join_queued = True
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_after_backward)
+        except RuntimeError:      # not inside a backward pass (a Function's backward called by hand)
+            _join_queued = False
 
 
 def join_side_streams():
@@ -533,6 +571,8 @@ class GradStash(torch.autograd.Function):
             raise RuntimeError("GradStash: the consumer of this slot ran before the gradient was parked (the stash node must be "
                                "created after the consuming layer's node, on the same stream)")
         ctx.slot.append(g)
+        _stash_watch.append(ctx.slot)
+        ensure_join_after_backward()
         return None, None
 
 

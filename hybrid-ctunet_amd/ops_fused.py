@@ -378,6 +378,7 @@ class _BwdRun:
         self.side = None
         if self.direct and ops.WGRAD_STREAM and any(t[0] is not None for t in targets):
             self.side = ops.side_stream(device, ("wgrad", self.s0))
+            ops.ensure_join_after_backward()
         self.s1 = self.side.cuda_stream if self.side is not None else self.s0
 
     def ws_values(self, need: _Need):
@@ -909,10 +910,15 @@ def _ff_params(net):
     return [net[0].weight, net[0].bias, net[1].weight, net[1].bias, net[4].weight, net[4].bias]
 
 
+def _all_trainable(module) -> bool:
+    """The fused backward produces every parameter gradient of the block; a partly frozen block takes the per-op path."""
+    return not torch.is_grad_enabled() or all(p.requires_grad for p in module.parameters())
+
+
 def vit_trunk_ok(vit, x) -> bool:
     b0 = vit.transformer[0]
     drop = max(b0.attn.dropout.p, b0.attn.to_out[1].p, b0.ff.net[3].p, b0.ff.net[5].p)
-    return usable(x) and x.dim() == 3 and not (vit.training and drop > 0.0)
+    return usable(x) and x.dim() == 3 and not (vit.training and drop > 0.0) and _all_trainable(vit.transformer)
 
 
 def vit_trunk(blocks, x):
@@ -947,7 +953,7 @@ def up_stage_ok(x, blk, ind, training) -> bool:
         p = (f.to_out[1].p if hasattr(f, "to_out") else max(f.net[3].p, f.net[5].p))
         if training and p > 0.0:
             return False
-    return True
+    return _all_trainable(blk)
 
 
 def up_stage(blk, ind, x):
@@ -1281,7 +1287,8 @@ class PwaBlockFn(torch.autograd.Function):
 
 
 def pwa_block_ok(m, x1, x2) -> bool:
-    return usable(x1) and x2.is_contiguous() and x2.dtype == x1.dtype and x1.shape == x2.shape and x1.shape[-1] % 32 == 0
+    return (usable(x1) and x2.is_contiguous() and x2.dtype == x1.dtype and x1.shape == x2.shape and x1.shape[-1] % 32 == 0
+            and _all_trainable(m))
 
 
 def pwa_block(m, x1, x2):

@@ -773,3 +773,23 @@ def test_instance_norm_sign_mask_equals_reading_y(ops, dtype):
     assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
     assert (a[1].float() - b[1].float()).abs().max() <= 1e-2 * b[1].float().abs().max()   # fp64 atomics order in the sums
     assert (a[1] == b[1]).float().mean() > 0.99
+
+
+def test_grad_stash_without_its_consumer_raises(ops):
+    """A gradient parked by GradStash is added by a specific later layer's data-gradient kernel.  If that layer is not part of
+    the backward pass (here: only the stashed branch is differentiated) the gradient must not vanish silently."""
+    w = torch.nn.Parameter(torch.randn(32, 32, device="cuda") * 0.1)
+    x = torch.randn(64, 32, device="cuda", requires_grad=True)
+    slot = []
+    main = ops.linear(x, w, grad_stash=slot)          # the consumer: would add the parked gradient in its epilogue
+    side = ops.GradStash.apply(x, slot)                # the other consumer of x parks its gradient
+    with pytest.raises(RuntimeError, match="parked"):
+        (side * 2.0).sum().backward()                  # ... but only the side branch is backpropagated
+    slot2 = []
+    main = ops.linear(x, w, grad_stash=slot2)
+    side = ops.GradStash.apply(x, slot2)
+    x.grad = None
+    (main.sum() + (side * 2.0).sum()).backward()       # both: the parked gradient arrives through the consumer
+    torch.cuda.synchronize()
+    ref = (torch.ones(64, 32, device="cuda") @ w.detach()) + 2.0
+    assert torch.allclose(x.grad, ref, rtol=1e-3, atol=1e-3)
