@@ -192,10 +192,14 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (train.GraphedStep).  Off by default: on ROCm 7.2 the graph executor "
                          "serialises the captured streams (58 ms / step against 49 ms enqueued eagerly on four streams)")
-    ap.add_argument("--opt-overlap", action="store_true",
+    ap.add_argument("--opt-overlap", dest="opt_overlap", action="store_true", default=True,
                     help="per-bucket AdamW updates queued under the backward pass (FusedAdamW(overlap=True)) instead of one launch "
-                         "after backward().  Off by default: 47.95 - 47.98 against 48.00 - 48.20 ms per step - the update is HBM "
-                         "traffic and the step is bound by its total bytes, earlier does not make it less")
+                         "after backward(): same arithmetic, element for element.  Default since round 3: with the launch lists the "
+                         "host no longer paces the backward pass and the early updates fill its gaps (47.1 / 47.0 against 47.6 / "
+                         "47.5 ms per step, two A/B pairs on one box, profiles/r03_bench_ab_stream_options.log)")
+    ap.add_argument("--no-opt-overlap", dest="opt_overlap", action="store_false", help="one AdamW launch after backward()")
+    ap.add_argument("--enc0-stream", action="store_true",
+                    help="A/B: vit_encoder0 on a third HIP stream from the start of the forward pass (measured slower: off)")
     ap.add_argument("--route", type=int, default=0,
                     help="A/B measurements: ctu_set_option(\"route\", N) bit set (include/ctunet_hip.h); 0 = the shipped routing")
     ap.add_argument("--serial", action="store_true",
@@ -263,6 +267,7 @@ def main():
         opt.overlap_enabled = not flag
         if hasattr(model, "overlap_branches"):
             model.overlap_branches = not flag
+            model.enc0_stream = bool(a.enc0_stream) and not flag
     set_serial(a.serial)
 
     def step():

@@ -475,13 +475,14 @@ class _VitBranch(_Base):
         """ViT trunk + window-attention pyramid (hybrid_CTUNet.py:821,824): [768@6.6.12, 512@12.12.24, ..., 64@96^3]."""
         return self.vit_encoder(self.proj_feat(self.vit(x[..., 0])))
 
-    def _vit_heads(self, x, vit_enc):
-        """vit_encoder0 / vit_decoder0 and the two ViT-branch heads (hybrid_CTUNet.py:822,831-835)."""
+    def _vit_heads(self, x, vit_enc, enc0=None):
+        """vit_encoder0 / vit_decoder0 and the two ViT-branch heads (hybrid_CTUNet.py:822,831-835).  enc0: vit_encoder0(x) when
+        the caller has already computed it (CTUNet.forward runs it on a stream of its own)."""
         # vit_enc[4] is read by vit_decoder0 and by the 96 x 96 head: the head's gradient is parked and added inside the
         # data-gradient GEMM of vit_decoder0's shortcut conv (ResBlock.forward)
         top = vit_enc[4]
         st = [] if (torch.is_grad_enabled() and top.requires_grad and ops.STASH_SHORTCUT_CONV) else None
-        vit_out = self.vit_decoder0(top, self.vit_encoder0(x), grad_stash=st)
+        vit_out = self.vit_decoder0(top, enc0 if enc0 is not None else self.vit_encoder0(x), grad_stash=st)
         return self.vit_out(vit_out), self.decoder_linear_96x96(ops.GradStash.apply(top, st) if st is not None else top)
 
     def _vit_forward(self, x):
@@ -493,6 +494,9 @@ class _VitBranch(_Base):
 class CTUNet(_VitBranch):
     """networks/hybrid_CTUNet.py:694-857."""
     overlap_branches = True   # run the ResNet and the ViT encoder on two HIP streams (set False to serialise them)
+    enc0_stream = False       # vit_encoder0 on a third stream from the start of the forward pass: measured 50.1 - 53.7 ms per step
+                              # against 47.1 - 47.2 without (profiles/r03_bench_ab_stream_options.log): its 96^3 kernels then
+                              # share the chip with the first ResNet stages instead of filling gaps - off
 
     def __init__(self, in_channels: int, dim_conv_stem: int, out_channels: int, model_depth: int,
                  img_size: Tuple[int, int], frames: int, patch_frame: int, hidden_size: int = 768, num_depths: int = 12,
@@ -534,6 +538,18 @@ class CTUNet(_VitBranch):
             main = torch.cuda.current_stream()
             side = ops.side_stream(x.device)
             side.wait_stream(main)      # (recorded before the convnet is queued: the side stream starts with it, not after it)
+            # vit_encoder0 (a ResBlock on the 96^3 input, hybrid_CTUNet.py:822) needs the image only: it starts at once on a third
+            # stream, under the launch-latency-bound ViT trunk and the small ResNet stages, instead of behind the skip paths
+            enc0 = enc0_ready = None
+            if self.enc0_stream:
+                third = ops.side_stream(x.device, "enc0")
+                third.wait_stream(main)
+                with torch.cuda.stream(third):
+                    enc0 = self.vit_encoder0(x)
+                    enc0.record_stream(side)
+                    enc0_ready = torch.cuda.Event()
+                    enc0_ready.record(third)
+                x.record_stream(third)
             res_enc1, res_enc2, res_enc3, res_enc4 = self.convnet(x)
             feats_ready = torch.cuda.Event()
             feats_ready.record(main)
@@ -554,7 +570,9 @@ class CTUNet(_VitBranch):
                     ev.record(side)
                     skips.append(t)
                     skip_ready.append(ev)
-                vit_logits, vit_96x96 = self._vit_heads(x, vit_enc)   # needed by the loss only
+                if enc0_ready is not None:
+                    side.wait_event(enc0_ready)
+                vit_logits, vit_96x96 = self._vit_heads(x, vit_enc, enc0)   # needed by the loss only
                 for t in (vit_logits, vit_96x96):
                     t.record_stream(main)
             x.record_stream(side)
