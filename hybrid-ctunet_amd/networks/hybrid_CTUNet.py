@@ -62,7 +62,8 @@ class ResBlock(nn.Module):
         # (GradStash on conv3's inputs) and added inside conv1's data-gradient kernel - no autograd accumulation pass over
         # three full-size tensors per input (680 MB each at vit_decoder0)
         stash1 = stash2 = None
-        if self.downsample and ops.STASH_SHORTCUT_CONV and torch.is_grad_enabled() and ops._halo_ok(self.conv1.kernel_size, self.conv1.stride, self.conv1.padding):
+        if (self.downsample and ops.STASH_SHORTCUT_CONV and torch.is_grad_enabled() and self.conv1.in_channels != 1
+                and ops._halo_ok(self.conv1.kernel_size, self.conv1.stride, self.conv1.padding)):   # (a one-channel input is the image: no gradient flows to it)
             stash1 = [] if inp.requires_grad else None
             stash2 = [] if (inp2 is not None and inp2.requires_grad) else None
         if grad_stash is not None and stash is not None:
