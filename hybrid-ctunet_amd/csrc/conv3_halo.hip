@@ -1304,6 +1304,68 @@ __global__ __launch_bounds__(256) void pack_frag_batched_kernel(const ctu_pack_j
   const ctu_pack_job jb = jobs[lo];
   const float* __restrict__ src = jb.src;
   const int64_t nblk = (lo + 1 < count ? jobs[lo + 1].block0 : (int64_t)gridDim.x) - jb.block0;
+  // 27-tap bf16 panels of nn.Conv3d weights (every job of a training step): a workgroup takes (32 n x 32 c) tiles with all 27
+  // taps.  The source is read as 32 runs of 864 contiguous floats - the (c, t) run of one output channel for the forward
+  // panel (sc == 27), the (n', t) run of one reduction channel for the data-gradient panel (sn == 27) - i.e. every byte once
+  // and coalesced; the element-per-thread loop below reads 4 bytes 108 bytes apart and fetches every line ~16 times (345 us
+  // per step for 220 MB of weights).  The transposition to fragment order goes through LDS (rows padded to an odd dword count).
+  if (jb.dst_dtype == CTU_BF16 && jb.taps == 27 && jb.st == 1 && (jb.sc == 27 || jb.sn == 27)) {
+    constexpr int ROW = 32 * 27 + 2;
+    __shared__ bf16 tile[32 * ROW];
+    const bool fwd = jb.sc == 27;          // runs over (c, t) for fixed n; else over (n', t) for fixed c'
+    const int chunks = jb.K >> 5;
+    const int ntiles = jb.ntn * chunks;
+    bf16* __restrict__ dstb = reinterpret_cast<bf16*>(jb.dst);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int tl = (int)((int64_t)blockIdx.x - jb.block0); tl < ntiles; tl += (int)nblk) {
+      const int nt = tl % jb.ntn, chunk = tl / jb.ntn;
+      const int n0 = nt * 32, c0 = chunk * 32;
+      __syncthreads();   // the previous tile's readers are done
+      // 27 float4 per thread (the runs are 16-byte aligned: K % 32 == 0), nine independent loads in flight at a time (one
+      // dependent 4-byte load per iteration made a tile cost ~100 us of pure latency)
+#pragma unroll 1
+      for (int k0 = 0; k0 < 27; k0 += 9) {
+        f32x4 v[9];
+        int run[9], q[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+          const int e = threadIdx.x + 256 * (k0 + u);
+          run[u] = e / 216;
+          q[u] = (e - run[u] * 216) * 4;
+          const int n_l = fwd ? run[u] : 0;   // (the data-gradient runs mix n' inside: bounds per element below)
+          const float* g = fwd ? src + (int64_t)(n0 + n_l) * jb.sn + (int64_t)c0 * 27 + q[u]
+                               : src + (int64_t)(c0 + run[u]) * jb.sc + (int64_t)n0 * 27 + q[u];
+          const bool ok = fwd ? n0 + n_l < jb.N : n0 + (q[u] + 3) / 27 < jb.N;   // whole vector inside the parameter
+          v[u] = ok ? *reinterpret_cast<const f32x4*>(g) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if (!ok && !fwd) {   // ragged end of a data-gradient run (N % 32 != 0): element by element
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (n0 + (q[u] + i) / 27 < jb.N) v[u][i] = g[i];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = q[u] + i;
+            const int inner = r / 27, t = r - inner * 27;
+            const int n_l = fwd ? run[u] : inner, c_l = fwd ? inner : run[u];
+            tile[n_l * ROW + c_l * 27 + (jb.flip ? 26 - t : t)] = (bf16)v[u][i];
+          }
+        }
+      }
+      __syncthreads();
+      for (int f = wave; f < 54; f += 4) {
+        const int tap = f >> 1, kk = f & 1;
+        const bf16* t0 = tile + (lane & 31) * ROW + (kk * 16 + 8 * (lane >> 5)) * 27 + tap;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = t0[j * 27];
+        *reinterpret_cast<bf16x8*>(dstb + ((((int64_t)chunk * 27 + tap) * 2 + kk) * jb.ntn + nt) * 512 + lane * 8) = o;
+      }
+    }
+    return;
+  }
   for (int64_t i = ((int64_t)blockIdx.x - jb.block0) * 256 + threadIdx.x; i < jb.total; i += nblk * 256) {
     const int j = (int)(i & 7);
     const int lane = (int)((i >> 3) & 63);
