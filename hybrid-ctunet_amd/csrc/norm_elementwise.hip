@@ -1186,22 +1186,31 @@ extern "C" int ctu_pwa_bwd(ctu_dtype dtype, const void* qkv1, const void* qkv2, 
 // VALU-bound direct convolution at a tenth of the VALU peak), weight gradient dW = dY^T P.  bf16; the image is a few
 // MB and stays in L2, the pass is bound by writing P (16 B per thread).
 // =========================================================================================================
+// One thread writes a whole row of P (kpad / 8 vectors): the row's output coordinate is decomposed once, the taps advance by
+// increment with carry, the image reads (L2-resident) of neighbouring rows overlap.  (One thread per 16-byte vector paid nine
+// integer divisions for eight 2-byte reads: 164 us for the 340 MB of the stem's patch matrix, 3x its store time.)
 __global__ __launch_bounds__(256) void im2col_cin1_kernel(const bf16* __restrict__ x, bf16* __restrict__ P, const ctu_geom g,
-                                                          const int taps, const int kpad, const int64_t total) {
+                                                          const int taps, const int kpad, const int64_t M) {
   const int kg = kpad >> 3;  // 8-tap groups per row
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+  // lanes of a wave take CONSECUTIVE vectors of P (coalesced 16-byte stores): vector i = (row, group); a thread keeps one group
+  // index and walks down the rows, so only the row index is decomposed per iteration (three divisions)
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;   // a multiple of kg (host): the thread's group never changes
+  const int grp = (int)(i0 % kg);
+  const int k0 = grp * 8;
+  int tw0 = k0 % g.kw;
+  const int tq = k0 / g.kw;
+  int th0 = tq % g.kh, td0 = tq / g.kh;
+  const int64_t total = M * kg;
+  for (int64_t i = i0; i < total; i += stride) {
     const int64_t m = i / kg;
-    const int k0 = (int)(i - m * kg) * 8;
     int t = (int)m;
     const int ow = t % g.Wo; t /= g.Wo;
     const int oh = t % g.Ho; t /= g.Ho;
     const int od = t % g.Do;
     const int b = t / g.Do;
     bf16x8 v;
-    // first tap of the group decomposed once, the next seven by increment with carry
-    int tw = k0 % g.kw;
-    int tq = k0 / g.kw;
-    int th = tq % g.kh, td = tq / g.kh;
+    int tw = tw0, th = th0, td = td0;
     const int bd = od * g.sd - g.pd, bh = oh * g.sh - g.ph, bw = ow * g.sw - g.pw;
     const bf16* xb = x + (size_t)b * g.Di * g.Hi * g.Wi;
 #pragma unroll
@@ -1225,7 +1234,11 @@ extern "C" int ctu_im2col_cin1(const void* x, void* P, const ctu_geom* g, int32_
   const int64_t M = (int64_t)g->B * g->Do * g->Ho * g->Wo;
   CTU_REQUIRE(M < (1ll << 31), "im2col_cin1: too many rows");
   const int64_t total = M * (kpad / 8);
-  hipLaunchKernelGGL(im2col_cin1_kernel, dim3(grid_for(total, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16*)x, (bf16*)P, *g, taps, kpad, total);
+  const int kg = kpad / 8;
+  int64_t grid = (total + 255) / 256;
+  if (grid > 16384) grid = 16384;
+  grid = (grid + kg - 1) / kg * kg;   // grid x 256 a multiple of kg: a thread keeps its tap group
+  hipLaunchKernelGGL(im2col_cin1_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)x, (bf16*)P, *g, taps, kpad, M);
   return ctu_check_launch("im2col_cin1");
 }
