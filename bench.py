@@ -249,7 +249,10 @@ def main():
     use_graph = world == 1 and a.graph and not a.serial
     # the optimizer updates a bucket of parameters as soon as its gradients are final (behind the bucket's all-reduce for N > 1):
     # same arithmetic as one update after backward(), queued under the rest of the backward pass (train.FusedAdamW)
-    opt_overlap = a.opt_overlap and not (a.serial or use_graph)
+    # (N > 1: the per-bucket update behind each bucket's all-reduce - DataParallel.attach_optimizer - has run over gloo on one GPU
+    #  only; the first runs over RCCL keep the plain finish() + step() sequence unless --opt-overlap is given explicitly)
+    explicit = "--opt-overlap" in sys.argv
+    opt_overlap = a.opt_overlap and not (a.serial or use_graph) and (world == 1 or explicit)
     opt = H.FusedAdamW(None, lr=1e-4, weight_decay=1e-5, flat=flat, capturable=use_graph, overlap=opt_overlap and world == 1)
     if dp is not None and opt_overlap:
         dp.attach_optimizer(opt)
