@@ -65,7 +65,13 @@ def side_streams(device):
 # waits for: with a training harness that owns the gradient storage (direct sinks) they are queued on a companion stream
 # of the layer's compute stream and overlap the data-gradient chain - the small-volume stages and the 864-token ViT
 # trunk are launch-latency bound, two kernels side by side fill what one leaves idle.  The optimizer joins the streams.
-WGRAD_STREAM = not os.environ.get("CTU_NO_WGRAD_STREAM")
+# Round 3: OFF by default.  With the launch lists the host no longer paces the backward pass and the companion streams buy nothing
+# (46.86 vs 46.89 ms per step); what they do add is a dependence on how HIP maps streams to its hardware queues: with
+# GPU_MAX_HW_QUEUES >= 5 every stream gets a queue of its own, the HBM-bound per-bucket optimizer updates and the weight-gradient
+# kernels then run truly beside the backward pass, and the step takes 66 - 67 ms instead of 47 (profiles/r03_bench_hw_queues_sweep.log;
+# co-residency of matrix-bound and memory-bound kernels is what this chip does worst).  CTU_WGRAD_STREAM=1
+# switches them back on.
+WGRAD_STREAM = bool(os.environ.get("CTU_WGRAD_STREAM")) and not os.environ.get("CTU_NO_WGRAD_STREAM")
 
 
 class _WgradSide:

@@ -9,8 +9,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(block, x, gy, fused, flat=None):
-    from hybrid_ctunet_amd import ops_fused as F
+    from hybrid_ctunet_amd import ops, ops_fused as F
     F.ENABLED = fused
+    wg = ops.WGRAD_STREAM
+    ops.WGRAD_STREAM = flat is not None   # with gradient sinks: weight-gradient kernels on the companion stream (plan events)
     try:
         if flat is not None:
             flat.zero_grad()
@@ -27,6 +29,7 @@ def _run(block, x, gy, fused, flat=None):
         return out.detach().clone(), [t.grad.detach().clone() for t in xs], grads
     finally:
         F.ENABLED = True
+        ops.WGRAD_STREAM = wg
 
 
 def _close(a, b, name, tol=2e-2, same=0.98):
