@@ -253,10 +253,6 @@ def main():
     #  only; the first runs over RCCL keep the plain finish() + step() sequence unless --opt-overlap is given explicitly)
     explicit = "--opt-overlap" in sys.argv
     opt_overlap = a.opt_overlap and not (a.serial or use_graph) and (world == 1 or explicit)
-    if opt_overlap and not explicit and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) > 4:
-        # with more than the default four hardware queues the update stream gets a queue of its own and its HBM-bound kernels
-        # run truly beside the backward pass: 66 ms per step instead of 47 (profiles/r03_bench_hw_queues_sweep.log)
-        opt_overlap = False
     opt = H.FusedAdamW(None, lr=1e-4, weight_decay=1e-5, flat=flat, capturable=use_graph, overlap=opt_overlap and world == 1)
     if dp is not None and opt_overlap:
         dp.attach_optimizer(opt)

@@ -298,7 +298,13 @@ class FusedAdamW:
                     begin, members = end, []
             self._ov = {"buckets": buckets, "of": {i: b for b, (_, _, mem) in enumerate(buckets) for i in mem},
                         "pending": [len(mem) for _, _, mem in buckets], "seen": [False] * len(f.params),
-                        "stream": torch.cuda.Stream(), "home": torch.cuda.current_stream()}
+                        # The updates are queued on the model's BRANCH stream (ops.side_stream: CTUNet's second encoder stream), not
+                        # on a stream of their own: in line with the ViT branch's backward, beside the main stream.  A dedicated
+                        # stream is 0.15 ms per step faster while HIP happens to map it onto a hardware queue it shares with
+                        # another stream (the default four queues) - and 19 ms slower when it gets a queue of its own
+                        # (GPU_MAX_HW_QUEUES >= 5: 66 ms per step, profiles/r03_bench_hw_queues_sweep.log): the 5.2 GB of
+                        # update traffic then run truly beside the backward pass.
+                        "stream": ops.side_stream(f.flat.device), "home": torch.cuda.current_stream()}
             f.listeners.append(self._on_ready)
 
     def set_lr(self, lr: float):
