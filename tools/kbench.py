@@ -157,6 +157,8 @@ CASES = {
                             halo(2, 24, 24, 48, 256, 256, "fwd"), call("ctu_set_option", b"nt_debug", 0)) for d in (0, 4, 8, 12)],
     "inorm": lambda: [inorm(2, 96, 96, 96, 64), inorm(2, 48, 48, 96, 128), inorm(2, 48, 48, 96, 512), inorm(2, 24, 24, 48, 256),
                       inorm(2, 24, 24, 48, 1024), inorm(2, 48, 48, 96, 32)],
+    "inorm_small": lambda: [inorm(2, 12, 12, 24, 128, sets=8), inorm(2, 12, 12, 24, 512, sets=8), inorm(2, 24, 24, 48, 64, sets=8),
+                            inorm(2, 24, 24, 48, 256, sets=8), inorm(2, 6, 6, 12, 256, sets=8), inorm(2, 6, 6, 12, 1024, sets=8)],
     "wgrad_debug": lambda: [(call("ctu_set_option", b"nt_debug", d), print("nt_debug =", d),
                              halo(2, 96, 96, 96, 64, 64, "wgrad"), halo(2, 48, 48, 96, 128, 128, "wgrad"),
                              halo(2, 24, 24, 48, 256, 256, "wgrad"), call("ctu_set_option", b"nt_debug", 0)) for d in (0, 4, 1, 5)],

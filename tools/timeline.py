@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Concurrency picture of one profiled run: python tools/timeline.py <kernel_trace.csv> [skip_fraction]
+"""Concurrency picture of one profiled run: python tools/timeline.py <kernel_trace.csv> [skip_fraction | marker:first:steps:per_step]
+(marker form: the window runs from the start of launch number first * per_step of the kernel whose name contains `marker` to the
+start of launch (first + steps) * per_step - whole steps, e.g. im2col_cin1:4:5:2 = five steps from the fifth on)
 Reads rocprofv3 --kernel-trace CSV (Start_Timestamp / End_Timestamp / Queue_Id / Kernel_Name), drops the first
 skip_fraction of the time span (warm-up) and prints: wall span, busy time (union of kernel intervals), time with
 1 / 2 / 3+ kernels in flight, idle gaps, and per kernel name the time it ran ALONE (nothing else on the device)."""
@@ -8,15 +10,23 @@ import sys
 from collections import defaultdict
 
 path = sys.argv[1]
-skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.45
+win = sys.argv[2] if len(sys.argv) > 2 else "0.45"
 rows = []
 for r in csv.DictReader(open(path)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0")))
 rows.sort()
 t0, t1 = rows[0][0], max(r[1] for r in rows)
-cut = t0 + int((t1 - t0) * skip)
-rows = [r for r in rows if r[0] >= cut]
-t0, t1 = rows[0][0], max(r[1] for r in rows)
+if ":" in win:
+    marker, first, nsteps, per = win.split(":")
+    marks = [r[0] for r in rows if marker in r[2]]
+    cut, end = marks[int(first) * int(per)], marks[(int(first) + int(nsteps)) * int(per)]
+    rows = [r for r in rows if cut <= r[0] < end]
+    t0, t1 = cut, end
+    print(f"window: {nsteps} steps, {(t1 - t0) / 1e6 / int(nsteps):.2f} ms per step")
+else:
+    cut = t0 + int((t1 - t0) * float(win))
+    rows = [r for r in rows if r[0] >= cut]
+    t0, t1 = rows[0][0], max(r[1] for r in rows)
 events = []
 for i, (s, e, n, q) in enumerate(rows):
     events.append((s, 1, i))
