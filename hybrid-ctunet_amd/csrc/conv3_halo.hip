@@ -1126,26 +1126,41 @@ __global__ __launch_bounds__(256) void halo_wgrad_reduce_kernel(const float* __r
   }
 }
 
-// Sum of the per-split partial panels part[split][27][NK], ADDED into the parameter layout dw[NK][27].  Workgroup (x, t) owns
-// 64 consecutive (n, k) pairs of tap t: the four waves share the splits (256 contiguous bytes per read), one LDS exchange,
-// then 64 read-modify-writes 108 bytes apart.  The partials are the traffic (splits x panel: 57 MB at 64 -> 64 @ 96^3, 128
-// splits), so the grid has to be wide - NK / 64 x 27 workgroups; the scattered 4-byte updates are a few hundred KB.
+// Sum of the per-split partial panels part[split][27][NK], ADDED into the parameter layout dw[NK][27].  A workgroup owns PAIRS
+// consecutive (n, k) pairs for ALL 27 taps: 256 / PAIRS split lanes per pair read rows of PAIRS x 4 contiguous bytes per (split, tap)
+// and keep 27 sums in registers; one LDS exchange; then the PAIRS x 27 results leave as ONE contiguous run of read-modify-writes.
+// (One workgroup per (64 pairs, tap) - the first version - updated 4-byte elements 108 bytes apart from 27 different workgroups: PMC
+// 36.6 MB written and 64 MB fetched per launch for panels of 0.1 - 28 MB, 4.6 GB per step, profiles/r03_pmc_hbm_traffic*.)
+template <int PAIRS>
 __global__ __launch_bounds__(256) void halo_wgrad_reduce_param_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                        const int64_t NK, const int splits) {
-  __shared__ float red[3][64];
-  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int t = blockIdx.y;
-  const int64_t nk = (int64_t)blockIdx.x * 64 + lane;
+  constexpr int SL = 256 / PAIRS;
+  __shared__ float red[SL][PAIRS * 27];
+  const int pl = threadIdx.x % PAIRS, g = threadIdx.x / PAIRS;
+  const int64_t nk0 = (int64_t)blockIdx.x * PAIRS;
+  const int64_t nk = nk0 + pl;
   const int64_t panel = 27 * NK;
-  float a = 0.f;
+  float a[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) a[t] = 0.f;
   if (nk < NK) {
-    const float* src = part + (int64_t)t * NK + nk;
-#pragma unroll 8
-    for (int sp = g; sp < splits; sp += 4) a += src[(int64_t)sp * panel];
+    for (int sp = g; sp < splits; sp += SL) {
+      const float* src = part + (int64_t)sp * panel + nk;
+#pragma unroll
+      for (int t = 0; t < 27; ++t) a[t] += src[(int64_t)t * NK];
+    }
   }
-  if (g > 0) red[g - 1][lane] = a;
+#pragma unroll
+  for (int t = 0; t < 27; ++t) red[g][pl * 27 + t] = a[t];
   __syncthreads();
-  if (g == 0 && nk < NK) dw[nk * 27 + t] += a + red[0][lane] + red[1][lane] + red[2][lane];
+  const int64_t left = NK - nk0;
+  const int total = (int)(left < PAIRS ? left : PAIRS) * 27;
+  for (int o = threadIdx.x; o < total; o += 256) {
+    float v = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < SL; ++gg) v += red[gg][o];
+    dw[nk0 * 27 + o] += v;
+  }
 }
 
 static int halo_wgrad_impl(ctu_dtype dtype, const void* dy, const void* x1, const void* x2, float* dw, int32_t B,
@@ -1224,7 +1239,8 @@ static int halo_wgrad_impl(ctu_dtype dtype, const void* dy, const void* x1, cons
     else hipLaunchKernelGGL(conv3_halo_wgrad_dma_kernel<1>, dim3(tiles * splits), dim3(512), 0, s, p);
     if (partials && param_layout) {
       const int64_t NK = (int64_t)N * (C1 + C2);
-      hipLaunchKernelGGL(halo_wgrad_reduce_param_kernel, dim3((unsigned)((NK + 63) / 64), 27), dim3(256), 0, s, ws, dw, NK, splits);
+      if (NK >= 32 * 512) hipLaunchKernelGGL(halo_wgrad_reduce_param_kernel<32>, dim3((unsigned)((NK + 31) / 32)), dim3(256), 0, s, ws, dw, NK, splits);
+      else hipLaunchKernelGGL(halo_wgrad_reduce_param_kernel<16>, dim3((unsigned)((NK + 15) / 16)), dim3(256), 0, s, ws, dw, NK, splits);
     } else if (partials) {
       if (panel >= 4 * 64 * 1024)
         hipLaunchKernelGGL(halo_wgrad_reduce_kernel<4>, dim3((unsigned)((panel / 4 + 63) / 64)), dim3(256), 0, s, ws, dw, panel, splits);

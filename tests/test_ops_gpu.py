@@ -711,6 +711,35 @@ def test_conv3d_halo_weight_gradient_partial_panels(ops, case):
     assert (a - c).abs().max().item() <= 2e-5 * scale + 1e-30
 
 
+@pytest.mark.parametrize("case", [(2, 8, 16, 16, 64, 64), (1, 5, 9, 11, 128, 128), (2, 4, 8, 8, 32, 32), (1, 8, 8, 16, 96, 72)])
+def test_conv3d_halo_weight_gradient_param_layout(ops, case):
+    """ctu_conv3_halo_wgrad_param adds the sum of the per-split partial panels straight into a gradient in the PARAMETER layout
+    [N][C][27] (one contiguous run of PAIRS x 27 elements per workgroup; 16 pairs per workgroup below 16 384 (n, c) pairs, else 32).
+    Against ctu_conv3_halo_wgrad (panel [27][N][C]) on the same operands and workspace: equal to fp32 rounding of the split sums,
+    the previous content of the gradient kept (+=), two runs bit-equal."""
+    from hybrid_ctunet_amd import _lib
+    from hybrid_ctunet_amd._lib import call, dcode, ptr, stream
+    B, D, H, W, C, N = case
+    x = rnd((B, D, H, W, C), 61).to(torch.bfloat16).cuda()
+    dy = rnd((B, D, H, W, N), 62).to(torch.bfloat16).cuda()
+    ws = torch.empty(64 << 20, device="cuda")
+    panel = torch.zeros(27, N, C, device="cuda")
+    call("ctu_conv3_halo_wgrad", dcode(torch.bfloat16), ptr(dy), ptr(x), None, ptr(panel), B, D, H, W, C, 0, N, 0, 0, ptr(ws),
+         ws.numel(), stream())
+    base = rnd((N, C, 27), 63).float().cuda()
+    outs = []
+    for _ in range(2):
+        g = base.clone()
+        call("ctu_conv3_halo_wgrad_param", dcode(torch.bfloat16), ptr(dy), ptr(x), None, ptr(g), B, D, H, W, C, 0, N, 0, 0, ptr(ws),
+             ws.numel(), stream())
+        torch.cuda.synchronize()
+        outs.append(g)
+    assert torch.equal(outs[0], outs[1])
+    want = base + panel.permute(1, 2, 0)
+    scale = panel.abs().max().item()
+    assert (outs[0] - want).abs().max().item() <= 2e-5 * scale + 1e-6
+
+
 @pytest.mark.parametrize("two", [False, True])
 def test_resblock_conv_shortcut_gradients_folded_into_conv1(ops, two):
     """ResBlock with a conv shortcut (in != out channels): conv3 reads the same input (or channel-concatenated pair of inputs) as
