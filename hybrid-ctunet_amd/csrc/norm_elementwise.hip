@@ -356,7 +356,11 @@ static int64_t in_rows_per_block(int64_t S, int B, int C = 2048) {
   int64_t chunks = total / (B > 0 ? B : 1);
   if (chunks < 1) chunks = 1;
   int64_t rows = (S + chunks - 1) / chunks;
-  if (rows < 64) rows = 64;
+  // small volumes with many channels (12 x 12 x 24 x 512, 6 x 6 x 12 x 1024): four row lanes per workgroup walk 64 rows one after
+  // the other - the pass is as long as that chain (1024 ch @ 6 x 6 x 12: 21.0 us, 9.2 with 16 rows per workgroup).  Elsewhere more
+  // workgroups only add atomics per address (256 ch @ 24 x 24 x 48: 23 -> 47 us); profiles/r03_kb_inorm_small_rows_floor.log
+  const int64_t floor_rows = (S <= 4096 && C >= 256 && !(ctu_option_route() & CTU_ROUTE_IN_ROWS64)) ? 16 : 64;
+  if (rows < floor_rows) rows = floor_rows;
   return rows;
 }
 
