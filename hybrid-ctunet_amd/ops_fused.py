@@ -31,7 +31,9 @@ ENABLED = not os.environ.get("CTU_NO_PLANS")
 # A/B switches for measurements (CTU_OPT="gelu2=0,acc=0": comma-separated name=0/1; read once at import, part of every plan key)
 OPT = {"gelu2": 1,    # GELU backward inside the data-gradient GEMM of the Linear behind it (ctu_epilogue.act = 2)
        "acc": 1,      # InstanceNorm finalize folded into the apply kernel (ctu_in_apply_acc)
-       "wparam": 1}   # halo weight gradients reduced straight into the parameter layout (ctu_conv3_halo_wgrad_param)
+       "wparam": 1,   # halo weight gradients reduced straight into the parameter layout (ctu_conv3_halo_wgrad_param)
+       "nogres": 1}   # blocks with a conv + norm shortcut: that norm's backward reads the block's gradient and sign mask itself
+                      # instead of a copy with the LeakyReLU slope applied, written by the main norm's backward (one tensor pass)
 for _kv in filter(None, os.environ.get("CTU_OPT", "").split(",")):
     _k, _, _v = _kv.partition("=")
     if _k not in OPT:
@@ -470,7 +472,8 @@ class _BneckPlan:
         F.add("st", 4 * 8192 * 4)      # four (mean, rstd) tables, 32 KiB apart
         F.add("mask", Mo * N4 // 8)
         G = self.gbufs = _Bufs("G")    # backward temporaries
-        G.add("g3", Mo * N4 * 2), G.add("gres", Mo * N4 * 2), G.add("ga2", Mo * P * 2), G.add("g2", Mo * P * 2)
+        G.add("g3", Mo * N4 * 2), G.add("ga2", Mo * P * 2), G.add("g2", Mo * P * 2)
+        G.add("gres", Mo * N4 * 2 if not (has_down and OPT["nogres"]) else 256)
         G.add("ga1", Mi * P * 2), G.add("g1", Mi * P * 2)
         if has_down:
             G.add("gd", Mo * N4 * 2), G.add("gxd", Mi * Cin * 2)
@@ -520,7 +523,8 @@ class _BneckPlan:
         need = self.need
         nb = _InBwd(R)
         # gn3 (+ residual + LeakyReLU): dy -> g3 (w.r.t. conv3's output) and gres (w.r.t. the shortcut)
-        nb.emit(R["gy"], y3, None, st[2], g3, gres, B, c3.So, N4, 1, 0, R["mask"])
+        direct = cd is not None and OPT["nogres"]   # the shortcut norm applies mask and slope to gy itself: no gres tensor
+        nb.emit(R["gy"], y3, None, st[2], g3, None if direct else gres, B, c3.So, N4, 1, 0, R["mask"])
         em_conv_dgrad(R, need, c3, g3, R["w3d"], ga2, None)
         if need_w[2]:
             em_conv_wgrad(R, need, c3, g3, a2, None, R["gw3"], stream=_wg_stream(R, side))
@@ -532,7 +536,10 @@ class _BneckPlan:
         extra = gres
         if cd is not None:
             gd, gxd = R["gd"], R["gxd"]
-            nb.emit(gres, R["yd"], None, st[3], gd, None, B, cd.So, N4, 0, 0)
+            if direct:
+                nb.emit(R["gy"], R["yd"], None, st[3], gd, None, B, cd.So, N4, 1, 0, R["mask"])
+            else:
+                nb.emit(gres, R["yd"], None, st[3], gd, None, B, cd.So, N4, 0, 0)
             em_conv_dgrad(R, need, cd, gd, R["wdd"], gxd, None)
             if need_w[3]:
                 em_conv_wgrad(R, need, cd, gd, R["x"], None, R["gwd"], stream=_wg_stream(R, side))
@@ -1012,7 +1019,8 @@ class _ResBlockPlan:
         F.add("st", 3 * 8192 * 4)
         F.add("mask", M * N // 8)
         G = self.gbufs = _Bufs("G")
-        G.add("g2", M * N * 2), G.add("gres", M * N * 2), G.add("ga1", M * N * 2), G.add("g1", M * N * 2)
+        G.add("g2", M * N * 2), G.add("ga1", M * N * 2), G.add("g1", M * N * 2)
+        G.add("gres", M * N * 2 if not (has_down and OPT["nogres"]) else 256)
         if has_down:
             G.add("g3", M * N * 2), G.add("gs1", M * C1 * 2)
             if C2:
@@ -1061,7 +1069,8 @@ class _ResBlockPlan:
         need = self.need
         nb = _InBwd(R)
         # norm2 (+ residual + LeakyReLU)
-        nb.emit(R["gy"], R["y2"], None, st[1], R["g2"], R["gres"], B, S, N, 1, c2.gy_b16, R["mask"])
+        direct = c3 is not None and OPT["nogres"]   # (as in the bottleneck: norm3's backward takes gy + mask)
+        nb.emit(R["gy"], R["y2"], None, st[1], R["g2"], None if direct else R["gres"], B, S, N, 1, c2.gy_b16, R["mask"])
         em_conv_dgrad(R, need, c2, R["g2"], R["w2d"], R["ga1"], None, gy_b16=c2.gy_b16)
         if need_w[1]:
             em_conv_wgrad(R, need, c2, R["g2"], R["a1"], None, R["gw2"], stream=_wg_stream(R, side), x1_b16=self.a1_b16,
@@ -1070,7 +1079,10 @@ class _ResBlockPlan:
         ext = R["ext"] if has_ext else None
         if c3 is not None:
             # conv shortcut: norm3 (no activation) -> conv3's data gradients, folded into conv1's data-gradient epilogue
-            nb.emit(R["gres"], R["y3"], None, st[2], R["g3"], None, B, S, N, 0, 0)
+            if direct:
+                nb.emit(R["gy"], R["y3"], None, st[2], R["g3"], None, B, S, N, 1, 0, R["mask"])
+            else:
+                nb.emit(R["gres"], R["y3"], None, st[2], R["g3"], None, B, S, N, 0, 0)
             gs2 = R["gs2"] if self.C2 else None
             em_conv_dgrad(R, need, c3, R["g3"], R["w3d"], R["gs1"], gs2, extra=ext)
             if need_w[2]:
