@@ -79,6 +79,8 @@ _SIGS = {
     "ctu_pwa_bwd": [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "ctu_patchify": [_i32, _vp, _vp] + [_i32] * 7 + [_vp],
     "ctu_pixel_shuffle": [_i32, _vp, _vp] + [_i32] * 9 + [_vp],
+    "ctu_upsample2_zeros": [_i32, _vp, _vp] + [_i32] * 5 + [_vp],
+    "ctu_add_strided2": [_i32, _vp, _vp] + [_i32] * 5 + [_vp],
     "ctu_dicece_fwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp] + [_i32] * 8 + [_vp, _vp],
     "ctu_dicece_finalize": [_vp, _i32, _i32, _i64, _f32, _f32, _f32, _vp, _vp],
     "ctu_dicece_bwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp] + [_i32] * 8 + [_vp, _f32, _f32, _f32, _vp, _vp, _vp],

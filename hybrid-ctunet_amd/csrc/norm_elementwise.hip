@@ -1071,6 +1071,78 @@ extern "C" int ctu_pixel_shuffle(ctu_dtype dtype, const void* x, void* y, int32_
 }
 
 // =========================================================================================================
+// Stride-2 helpers of the data gradients of the ResNet stage transitions (resnet.py:98 conv2 with stride 2, resnet.py:166-176 the
+// strided 1x1x1 downsample).  The generic implicit GEMM computed them per INPUT voxel with 7 of 8 taps masked (25 - 47 TFLOP/s):
+//   * 3x3x3, stride 2, padding 1:  dX = conv3x3x3_stride1(U, flipped W) with U = dY zero-upsampled by 2 - eight times the MACs,
+//     but on the halo kernel (ctu_conv3_halo) they cost a fifth of the time; ctu_upsample2_zeros writes U.
+//   * 1x1x1, stride 2:  dX is dY W at the even voxels and zero elsewhere: a plain GEMM over the OUTPUT rows, then
+//     ctu_add_strided2 adds the compact result into the gradient it joins (the block input's) at the even voxels.
+// =========================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2_zeros_kernel(const T* __restrict__ x, T* __restrict__ y, const int B, const int D,
+                                                              const int H, const int W, const int C) {
+  const int ncg = C >> 3;
+  const int64_t total = (int64_t)B * 8 * D * H * W * ncg;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t t = i / ncg;
+    const int cg = (int)(i - t * ncg);
+    const int w = (int)(t % (2 * W)); t /= 2 * W;
+    const int h = (int)(t % (2 * H)); t /= 2 * H;
+    const int d = (int)(t % (2 * D));
+    const int b = (int)(t / (2 * D));
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (!((d | h | w) & 1)) load8(x + ((((size_t)b * D + (d >> 1)) * H + (h >> 1)) * W + (w >> 1)) * C + cg * 8, v);
+    store8(y + i * 8, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_strided2_kernel(T* __restrict__ y, const T* __restrict__ x, const int B, const int D,
+                                                           const int H, const int W, const int C) {
+  const int ncg = C >> 3;
+  const int64_t total = (int64_t)B * D * H * W * ncg;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t t = i / ncg;
+    const int cg = (int)(i - t * ncg);
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); t /= H;
+    const int d = (int)(t % D);
+    const int b = (int)(t / D);
+    T* dst = y + ((((size_t)b * 2 * D + 2 * d) * 2 * H + 2 * h) * 2 * W + 2 * w) * C + cg * 8;
+    float a[8], v[8];
+    load8(dst, a);
+    load8(x + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += v[e];
+    store8(dst, a);
+  }
+}
+
+extern "C" int ctu_upsample2_zeros(ctu_dtype dtype, const void* x, void* y, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C,
+                                   ctu_stream_t stream) {
+  CTU_REQUIRE(x && y && B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "upsample2_zeros: bad args (C %% 8)");
+  const unsigned grid = grid_for((int64_t)B * 8 * D * H * W * (C / 8), 256);
+  hipStream_t s = (hipStream_t)stream;
+  CTU_DISPATCH(dtype,
+               hipLaunchKernelGGL(upsample2_zeros_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, B, D, H, W, C),
+               hipLaunchKernelGGL(upsample2_zeros_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, B, D, H, W, C));
+  return ctu_check_launch("upsample2_zeros");
+}
+
+extern "C" int ctu_add_strided2(ctu_dtype dtype, void* y, const void* x, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C,
+                                ctu_stream_t stream) {
+  CTU_REQUIRE(x && y && B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "add_strided2: bad args (C %% 8)");
+  const unsigned grid = grid_for((int64_t)B * D * H * W * (C / 8), 256);
+  hipStream_t s = (hipStream_t)stream;
+  CTU_DISPATCH(dtype,
+               hipLaunchKernelGGL(add_strided2_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)y, (const float*)x, B, D, H, W, C),
+               hipLaunchKernelGGL(add_strided2_kernel<bf16>, dim3(grid), dim3(256), 0, s, (bf16*)y, (const bf16*)x, B, D, H, W, C));
+  return ctu_check_launch("add_strided2");
+}
+
+// =========================================================================================================
 // binary cross-weight fusion core (hybrid_CTUNet.py:651-665).  4 lanes per (token, head of 32 channels).
 // =========================================================================================================
 template <typename T>

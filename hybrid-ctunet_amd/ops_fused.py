@@ -32,6 +32,8 @@ ENABLED = not os.environ.get("CTU_NO_PLANS")
 OPT = {"gelu2": 1,    # GELU backward inside the data-gradient GEMM of the Linear behind it (ctu_epilogue.act = 2)
        "acc": 1,      # InstanceNorm finalize folded into the apply kernel (ctu_in_apply_acc)
        "wparam": 1,   # halo weight gradients reduced straight into the parameter layout (ctu_conv3_halo_wgrad_param)
+       "s2": 1,       # stride-2 data gradients of the stage transitions: 3x3x3 on the halo kernel over the zero-upsampled dY,
+                      # 1x1x1 as a plain GEMM over the output rows + ctu_add_strided2 (instead of the generic implicit GEMM)
        "nogres": 1}   # blocks with a conv + norm shortcut: that norm's backward reads the block's gradient and sign mask itself
                       # instead of a copy with the LeakyReLU slope applied, written by the main norm's backward (one tensor pass)
 for _kv in filter(None, os.environ.get("CTU_OPT", "").split(",")):
@@ -234,6 +236,15 @@ class ConvSpec:
         # may the norm behind this conv hand its input gradient over in CTU_LAYOUT_B16 (this conv's backward is its one reader)
         self.gy_b16 = bool(self.kind == "halo" and ops.B16_LAYOUT and big)
         self.wkn_d = self.kind == "lin" and N % 64 == 0 and self.K % 8 == 0
+        # stride-2 data gradients off the generic implicit GEMM (which masks 7 of 8 taps per input voxel: 25 - 47 TFLOP/s)
+        self.dgrad_via = None
+        even = all(n % 2 == 0 for n in din) and self.stride == (2, 2, 2) and C2 == 0 and OPT["s2"]
+        if self.kind == "gen" and even and self.k == (3, 3, 3) and self.padding == (1, 1, 1) and C1 % 32 == 0 and N % 32 == 0 \
+                and self.Mi * max(C1, N) < (1 << 31):
+            self.dgrad_via = "halo_up2"      # dX = conv3_halo(zero-upsampled dY, flipped W)
+        elif self.kind == "gen" and even and self.taps == 1 and self.padding == (0, 0, 0) and C1 % 8 == 0 and N % 32 == 0:
+            self.dgrad_via = "gemm_s2"       # compact dX = dY W over the output rows; the caller adds it at the even voxels
+            self.wkn_d = N % 64 == 0 and self.K % 8 == 0
 
     def wants_b16_input(self) -> bool:
         return bool(self.kind == "halo" and ops.B16_LAYOUT and self.C2 == 0 and self.Mi * max(self.C1, self.N) < (1 << 31))
@@ -256,7 +267,12 @@ def conv_weights(spec: ConvSpec, weight, fwd=True, dgrad=True):
     else:
         if fwd:
             wf = ops._packed(weight, "conv_f", dt, lambda: ops._pack(weight, (taps, N, K), (1, K * taps, taps), dt))
-        if dgrad:
+        if dgrad and spec.dgrad_via == "halo_up2":
+            wd = ops._packed_frag(weight, "conv_hd", dt, K, N, taps, taps, K * taps, 1, 1)
+        elif dgrad and spec.dgrad_via == "gemm_s2":
+            wd = ops._linear_weight(weight, weight.reshape(N, K), dt) if spec.wkn_d else \
+                ops._packed(weight, "lin_d", dt, lambda: weight.detach().reshape(N, K).t().to(dt).contiguous())
+        elif dgrad:
             wd = ops._packed(weight, "conv_d", dt, lambda: ops._pack(weight, (taps, K, N), (1, taps, K * taps), dt))
     return wf, wd
 
@@ -281,9 +297,21 @@ def em_conv_fwd(R, need, spec: ConvSpec, x1, x2, w, out, *, x1_b16=0, acc=None):
     return s.fused_stats and acc is not None
 
 
-def em_conv_dgrad(R, need, spec: ConvSpec, gy, wd, g1, g2, *, extra=None, extra2=None, gy_b16=0):
-    """Data gradient of `spec`: g1 [Mi, C1] (and g2 [Mi, C2]) from gy [Mo, N]; extra / extra2 are added in the epilogue."""
+def em_conv_dgrad(R, need, spec: ConvSpec, gy, wd, g1, g2, *, extra=None, extra2=None, gy_b16=0, up2=None):
+    """Data gradient of `spec`: g1 [Mi, C1] (and g2 [Mi, C2]) from gy [Mo, N]; extra / extra2 are added in the epilogue.
+    up2: scratch [Mi, N] of a "halo_up2" spec.  A "gemm_s2" spec writes the COMPACT gradient [Mo, C1] into g1 (no extra)."""
     s = spec
+    if s.dgrad_via == "halo_up2":
+        assert g2 is None and extra2 is None and not gy_b16 and up2 is not None
+        B, (D, H, W), (Do, Ho, Wo) = s.B, s.din, s.dout
+        R.call("ctu_upsample2_zeros", BF16, gy, up2, B, Do, Ho, Wo, s.N)
+        R.call("ctu_conv3_halo", BF16, up2, None, wd, g1, None, B, D, H, W, s.N, 0, s.K, 0, s.C1, 0,
+               None, extra, None, R["tnws"], 1 << 24, 0)
+        return
+    if s.dgrad_via == "gemm_s2":
+        assert g2 is None and extra is None and extra2 is None and not gy_b16
+        em_gemm(R, need, gy, wd, g1, s.Mo, s.N, s.K, w_kn=1 if s.wkn_d else 0)
+        return
     if s.kind == "lin":
         assert g2 is None and extra2 is None
         em_gemm(R, need, gy, wd, g1, s.Mo, s.N, s.K, w_kn=1 if s.wkn_d else 0, residual=extra)
@@ -476,7 +504,9 @@ class _BneckPlan:
         G.add("gres", Mo * N4 * 2 if not (has_down and OPT["nogres"]) else 256)
         G.add("ga1", Mi * P * 2), G.add("g1", Mi * P * 2)
         if has_down:
-            G.add("gd", Mo * N4 * 2), G.add("gxd", Mi * Cin * 2)
+            G.add("gd", Mo * N4 * 2), G.add("gxd", (Mo if self.cd.dgrad_via == "gemm_s2" else Mi) * Cin * 2)
+        if self.c2.dgrad_via == "halo_up2":
+            G.add("up2", Mi * P * 2)       # conv2's dY zero-upsampled to its input's size
         assert B * N4 * 2 <= 8192
         self.need = _Need()
         self.fwd = None
@@ -529,11 +559,11 @@ class _BneckPlan:
         if need_w[2]:
             em_conv_wgrad(R, need, c3, g3, a2, None, R["gw3"], stream=_wg_stream(R, side))
         nb.emit(ga2, y2, None, st[1], g2, None, B, c2.So, P, 1, c2.gy_b16)
-        em_conv_dgrad(R, need, c2, g2, R["w2d"], ga1, None, gy_b16=c2.gy_b16)
+        em_conv_dgrad(R, need, c2, g2, R["w2d"], ga1, None, gy_b16=c2.gy_b16, up2=R["up2"] if c2.dgrad_via == "halo_up2" else None)
         if need_w[1]:
             em_conv_wgrad(R, need, c2, g2, a1, None, R["gw2"], stream=_wg_stream(R, side), x1_b16=self.a1_b16, gy_b16=c2.gy_b16)
         nb.emit(ga1, y1, None, st[0], g1, None, B, c1.So, P, 1, 0)
-        extra = gres
+        extra, compact = gres, None
         if cd is not None:
             gd, gxd = R["gd"], R["gxd"]
             if direct:
@@ -544,8 +574,12 @@ class _BneckPlan:
             if need_w[3]:
                 em_conv_wgrad(R, need, cd, gd, R["x"], None, R["gwd"], stream=_wg_stream(R, side))
             extra = gxd
+            if cd.dgrad_via == "gemm_s2":   # gxd holds the output rows only: added at the even voxels behind conv1's data gradient
+                extra, compact = None, gxd
         # conv1's data gradient takes the shortcut's gradient in its epilogue
         em_conv_dgrad(R, need, c1, g1, R["w1d"], R["gx"], None, extra=extra)
+        if compact is not None:
+            R.call("ctu_add_strided2", BF16, R["gx"], compact, B, *cd.dout, self.Cin)
         if need_w[0]:
             em_conv_wgrad(R, need, c1, g1, R["x"], None, R["gw1"], stream=_wg_stream(R, side))
         self.n_norms, self.last_n = nb.k, nb.prev

@@ -300,6 +300,16 @@ int ctu_pwa_fwd(ctu_dtype dtype, const void* qkv1, const void* qkv2, void* out, 
 int ctu_pwa_bwd(ctu_dtype dtype, const void* qkv1, const void* qkv2, const void* dout, void* dqkv1, void* dqkv2,
                 int64_t rows, int32_t C, float scale, ctu_stream_t stream);
 
+/* Stride-2 helpers of the stage-transition data gradients (resnet.py:98 conv2 with stride 2; resnet.py:166-176 downsample).
+ * upsample2_zeros: x [B][D][H][W][C] -> y [B][2D][2H][2W][C], y[b][2d][2h][2w] = x[b][d][h][w], zero elsewhere: the data gradient
+ *   of a 3x3x3 stride-2 padding-1 convolution is ctu_conv3_halo(y, flipped weights) at the input's size.
+ * add_strided2: y[b][2d][2h][2w][:] += x[b][d][h][w][:] for y [B][2D][2H][2W][C]: adds the (compact) data gradient of a 1x1x1
+ *   stride-2 convolution - a plain GEMM over its output rows - into the gradient of the tensor it read.  C % 8 == 0. */
+int ctu_upsample2_zeros(ctu_dtype dtype, const void* x, void* y, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C,
+                        ctu_stream_t stream);
+int ctu_add_strided2(ctu_dtype dtype, void* y, const void* x, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C,
+                     ctu_stream_t stream);
+
 /* K13 layout ops.  patchify: x [B][H][W][F] -> tokens [B][(H/p1)(W/p2)(F/p3)][p1*p2*p3]   (vit.py:115, c=1).
  * pixel shuffle: x [B][D][H][W][c*p1*p2*p3] -> y [B][D*p1][H*p2][W*p3][c]  (hybrid_CTUNet.py:420-428);
  * inverse = 1 applies the inverse map (its gradient). */
