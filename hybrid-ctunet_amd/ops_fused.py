@@ -332,9 +332,16 @@ def em_conv_dgrad(R, need, spec: ConvSpec, gy, wd, g1, g2, *, extra=None, extra2
                     splitk_ws=R["skws"] if sk > 1 else None))
 
 
-def em_conv_wgrad(R, need, spec: ConvSpec, gy, x1, x2, gw, *, stream, x1_b16=0, gy_b16=0):
-    """Weight gradient of `spec` accumulated into gw (fp32, the parameter's layout)."""
+def em_conv_wgrad(R, need, spec: ConvSpec, gy, x1, x2, gw, *, stream, x1_b16=0, gy_b16=0, up2=None):
+    """Weight gradient of `spec` accumulated into gw (fp32, the parameter's layout).  up2: the zero-upsampled dY of a "halo_up2"
+    spec (written by em_conv_dgrad): its weight gradient is the stride-1 halo weight gradient of (up2, x1)."""
     s = spec
+    if s.dgrad_via == "halo_up2" and up2 is not None and ops.WGRAD_PARTIALS and OPT["wparam"]:
+        assert not x1_b16 and not gy_b16 and x2 is None
+        B, (D, H, W) = s.B, s.din
+        R.call("ctu_conv3_halo_wgrad_param", BF16, up2, x1, None, gw, B, D, H, W, s.C1, 0, s.N, 0, 0,
+               R["wgws"], 256 * 54 * 1024 + 27 * 64 * 1024, stream=stream)
+        return
     if s.kind == "lin":
         R.call("ctu_igemm_tn", BF16, gy, s.N, x1, None, gw, None, ops._plain_geom(s.Mo, s.K, s.N), R["tnws1"], 1 << 24, stream=stream)
         return
@@ -561,7 +568,8 @@ class _BneckPlan:
         nb.emit(ga2, y2, None, st[1], g2, None, B, c2.So, P, 1, c2.gy_b16)
         em_conv_dgrad(R, need, c2, g2, R["w2d"], ga1, None, gy_b16=c2.gy_b16, up2=R["up2"] if c2.dgrad_via == "halo_up2" else None)
         if need_w[1]:
-            em_conv_wgrad(R, need, c2, g2, a1, None, R["gw2"], stream=_wg_stream(R, side), x1_b16=self.a1_b16, gy_b16=c2.gy_b16)
+            em_conv_wgrad(R, need, c2, g2, a1, None, R["gw2"], stream=_wg_stream(R, side), x1_b16=self.a1_b16, gy_b16=c2.gy_b16,
+                          up2=R["up2"] if c2.dgrad_via == "halo_up2" else None)
         nb.emit(ga1, y1, None, st[0], g1, None, B, c1.So, P, 1, 0)
         extra, compact = gres, None
         if cd is not None:
