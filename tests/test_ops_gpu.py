@@ -740,6 +740,36 @@ def test_conv3d_halo_weight_gradient_param_layout(ops, case):
     assert (outs[0] - want).abs().max().item() <= 2e-5 * scale + 1e-6
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 3, 5, 4, 32), (1, 6, 6, 12, 72)])
+def test_stride2_helpers(ops, dtype, shape):
+    """ctu_upsample2_zeros (y[2d][2h][2w] = x, zero elsewhere) and ctu_add_strided2 (y[2d][2h][2w] += x), and what the launch-list
+    path builds from the first: the data gradient of a 3x3x3 stride-2 padding-1 convolution = the stride-1 data gradient kernel
+    (ops.conv3d backward on the halo route) applied to the zero-upsampled dY."""
+    from hybrid_ctunet_amd._lib import call, dcode, ptr, stream
+    B, D, H, W, C = shape
+    x = rnd((B, D, H, W, C), 81).to(dtype).cuda()
+    up = torch.full((B, 2 * D, 2 * H, 2 * W, C), 7.0, dtype=dtype, device="cuda")
+    call("ctu_upsample2_zeros", dcode(dtype), ptr(x), ptr(up), B, D, H, W, C, stream())
+    want = torch.zeros_like(up)
+    want[:, ::2, ::2, ::2] = x
+    assert torch.equal(up, want)
+    y0 = rnd((B, 2 * D, 2 * H, 2 * W, C), 82).to(dtype).cuda()
+    y = y0.clone()
+    call("ctu_add_strided2", dcode(dtype), ptr(y), ptr(x), B, D, H, W, C, stream())
+    ref = y0.float()
+    ref[:, ::2, ::2, ::2] += x.float()
+    assert torch.equal(y, ref.to(dtype))
+    if C % 32 == 0 and dtype == torch.bfloat16:
+        w = torch.nn.Parameter(rnd((C, C, 3, 3, 3), 83, 1 / math.sqrt(27 * C)).float().cuda())
+        xin = rnd((B, 2 * D, 2 * H, 2 * W, C), 84).to(dtype).cuda().requires_grad_(True)
+        ops.conv3d(xin, w, 2, 1).backward(x)                     # generic implicit GEMM, strided data gradient
+        x1 = xin.detach().clone().requires_grad_(True)
+        ops.conv3d(x1, w, 1, 1).backward(up)                     # stride-1 (halo) data gradient of the upsampled dY
+        scale = xin.grad.float().abs().max().item()
+        assert (xin.grad.float() - x1.grad.float()).abs().max().item() <= 2 ** -7 * scale
+
+
 @pytest.mark.parametrize("two", [False, True])
 def test_resblock_conv_shortcut_gradients_folded_into_conv1(ops, two):
     """ResBlock with a conv shortcut (in != out channels): conv3 reads the same input (or channel-concatenated pair of inputs) as
