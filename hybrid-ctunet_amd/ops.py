@@ -1308,6 +1308,11 @@ def dropout_state() -> Tuple[int, int]:
 
 def _next_drop_key() -> Tuple[int, int]:
     global _drop_offset
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        # the (seed, offset) key is a kernel ARGUMENT taken from host state at launch time: a captured launch would replay the same
+        # mask forever, silently (GraphedStep / graph_stages with dropout_rate > 0)
+        raise RuntimeError("dropout with p > 0 cannot be captured into a HIP graph: the Philox key is a launch argument; run the "
+                           "step eagerly (the default) or set dropout_rate = 0")
     seed, off = dropout_state()
     _drop_offset = off + 1
     return seed, off

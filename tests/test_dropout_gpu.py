@@ -190,3 +190,25 @@ def test_tunet_trains_with_dropout_and_is_reproducible():
     ref.load_state_dict(net.state_dict())
     with torch.no_grad():
         assert l2(ref(x)[0].float(), e1) <= 8e-2
+
+
+def test_dropout_refuses_graph_capture():
+    """The Philox (seed, offset) key is a launch argument taken from host state: captured into a HIP graph, every replay would
+    reuse one mask without any error.  A dropout call with p > 0 on a capturing stream raises instead."""
+    x = torch.randn(64, 128, device=DEV).to(torch.bfloat16)
+    ops.dropout(x, 0.2)   # (warm: workspaces, seed)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    raised = False
+    with torch.cuda.stream(s):
+        g.capture_begin()
+        try:
+            ops.dropout(x, 0.2)
+        except RuntimeError as e:
+            raised = "cannot be captured" in str(e)
+        finally:
+            g.capture_end()
+    torch.cuda.current_stream().wait_stream(s)
+    assert raised
