@@ -240,11 +240,19 @@ __device__ __forceinline__ void halo_row_to_hw(int row, int& hh, int& ww) {
 // rule above).  HSP > 0 deals the burst over all four waves so that no wave reaches the next barriers later than the others by a
 // whole gather; a loader wave issues its pieces AFTER the weight stage of the same barrier, and for the RD - 1 barriers that follow
 // the pieces are younger than the awaited weights: those waits leave HSP more operations in flight (counted, not vmcnt(0)).
-template <int NT, int RD = (NT <= 2 ? 2 : 3), int TPS = 3, bool STAMP = false, int HSP = 4>
-__global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo_dma_kernel(const HaloArgs p) {
+// BP ("batch pair", volumes whose height is 4 or 12 mod 8, e.g. 12 x 12 x 24): the brick is 4 x 4 x 8 voxels of TWO batch items
+// (b = 2 pair + i for the wave's M tile i) instead of 4 x 8 x 8 of one - a 12-row volume then takes 3 bricks of 4 rows per pair of
+// items where it took 2 x 2 bricks of 8 rows, a quarter of them padding (36 -> 27 bricks at 2 x 12 x 12 x 24).  The halo image is two
+// 6 x 6 x 10 boxes (720 voxels, 23 DMA pieces; image row = 36 i + 6 hd + hh), everything else - weight stages, barriers, the M-tile
+// row order - is unchanged.
+template <int NT, int RD = (NT <= 2 ? 2 : 3), int TPS = 3, bool STAMP = false, int HSP = 4, bool BP = false>
+__global__ __launch_bounds__(256, (RD == 2 && TPS == 3 && !BP) ? 3 : 2) void conv3_halo_dma_kernel(const HaloArgs p) {
   unsigned long long st_t0 = 0, st_wait = 0, st_work = 0, st_pro = 0, st_mark = 0;
   if (STAMP) st_t0 = st_mark = __builtin_amdgcn_s_memtime();
-  constexpr int HINS = 19;            // DMA wave-instructions per halo half chunk (1216 slots >= 600 voxels x 2)
+  constexpr int BH = BP ? 4 : HB_H;                       // brick rows
+  constexpr int HH = BH + 2;                              // halo rows per d slice (and item)
+  constexpr int HVOX = (BP ? 2 : 1) * HALO_D * HH * HALO_W;   // 600 | 720
+  constexpr int HINS = (2 * HVOX + 63) / 64;          // DMA wave-instructions per halo half chunk: 19 (1216 slots >= 1200) | 23
   constexpr int HBUF = HINS * 1024;
   constexpr int SPC = 27 / TPS;       // stages per half chunk
   constexpr int SFR = TPS * NT;       // weight fragments (1 KiB each) per stage
@@ -263,8 +271,8 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
   const int bw = t % p.nbw; t /= p.nbw;
   const int bh = t % p.nbh; t /= p.nbh;
   const int bd = t % p.nbd;
-  const int b = t / p.nbd;
-  const int d0 = bd * HB_D, h0 = bh * HB_H, w0 = bw * HB_W;
+  const int b = (BP ? 2 : 1) * (t / p.nbd);   // BP: the first of the two batch items (p.nbh counts 4-row bricks then)
+  const int d0 = bd * HB_D, h0 = bh * BH, w0 = bw * HB_W;
   const int nt0 = blockIdx.y * NT;
   const int hc_b = blockIdx.z * p.hc_per_split;                      // this workgroup's range of 16-channel half chunks
   const int HC = min((p.C1 + p.C2) / 16, hc_b + p.hc_per_split);    // (exclusive end)
@@ -290,14 +298,16 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
   for (int k = 0; k < HPM; ++k) {
     const int S = (kbase + k) * 64 + lane;
     int m = -1;
-    if (S < 2 * HALO_VOX) {
+    if (S < 2 * HVOX) {
       const int vox = S >> 1, hs = S & 1;
-      const int R = vox / HALO_W, hw = vox - R * HALO_W;
-      const int hd = R / HALO_H, hh = R - hd * HALO_H;
+      const int R = vox / HALO_W, hw = vox - R * HALO_W;   // image row (BP: 36 item + 6 hd + hh)
+      const int item = BP ? R / (HALO_D * HH) : 0;
+      const int Ri = R - item * (HALO_D * HH);
+      const int hd = Ri / HH, hh = Ri - hd * HH;
       const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
       hpart |= (unsigned)(hs ^ ((R >> 1) & 1)) << k;
       if ((unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W)
-        m = ((b * p.D + gd) * p.H + gh) * p.W + gw;
+        m = (((b + item) * p.D + gd) * p.H + gh) * p.W + gw;
     }
     hm[k] = m;
   }
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
       int aoff[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int R = (wave + td) * HALO_H + 4 * i + vrow + th;
+        const int R = BP ? i * (HALO_D * HH) + (wave + td) * HH + vrow + th : (wave + td) * HALO_H + 4 * i + vrow + th;
         aoff[i] = ((R * HALO_W + vcol) * 2 + (h ^ ((R >> 1) & 1))) * 16;
       }
       // (measured: requesting the fragments of all three taps up front + s_setprio around the 6 NT MFMAs is 5-10 % SLOWER
@@ -450,11 +460,14 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
     // InstanceNorm statistics of this output, taken from the fp32 accumulators: the separate pass that re-reads the
     // tensor from HBM (in_stats_kernel) disappears.  Lane (r, h) sums its 2 x 16 rows of column r per n tile, the two
     // lane halves are combined by a shuffle, the four waves through LDS, then one fp64 atomic pair per channel and brick.
-    float* red = reinterpret_cast<float*>(smem + 20 * 1024);  // [4 waves][NT * 32 columns][2], beyond the staging tiles
-    const bool full = d0 + HB_D <= p.D && h0 + HB_H <= p.H && w0 + HB_W <= p.W;  // brick entirely inside the volume
+    float* red = reinterpret_cast<float*>(smem + 20 * 1024);  // [items][4 waves][NT * 32 columns][2], beyond the staging tiles
+    constexpr int NI = BP ? 2 : 1;   // batch items per brick: tile i belongs to item i (BP) or both tiles to the one item
+    const bool full = d0 + HB_D <= p.D && h0 + BH <= p.H && w0 + HB_W <= p.W;  // brick entirely inside the volume
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      float s1 = 0.f, s2 = 0.f;
+      float s1[NI], s2[NI];
+#pragma unroll
+      for (int it = 0; it < NI; ++it) { s1[it] = 0.f; s2[it] = 0.f; }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -463,30 +476,35 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
           if (!full) {
             int hh, ww;
             halo_row_to_hw((e & 3) + 8 * (e >> 2) + 4 * h, hh, ww);
-            if (d0 + wave >= p.D || h0 + 4 * i + hh >= p.H || w0 + ww >= p.W) v = 0.f;
+            if (d0 + wave >= p.D || h0 + (BP ? 0 : 4 * i) + hh >= p.H || w0 + ww >= p.W) v = 0.f;
           }
-          s1 += v;
-          s2 += v * v;
+          s1[BP ? i : 0] += v;
+          s2[BP ? i : 0] += v * v;
         }
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (h == 0) {
-        red[(wave * NT * 32 + j * 32 + r) * 2] = s1;
-        red[(wave * NT * 32 + j * 32 + r) * 2 + 1] = s2;
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const float a1 = s1[it] + __shfl_xor(s1[it], 32, 64), a2 = s2[it] + __shfl_xor(s2[it], 32, 64);
+        if (h == 0) {
+          red[((it * 4 + wave) * NT * 32 + j * 32 + r) * 2] = a1;
+          red[((it * 4 + wave) * NT * 32 + j * 32 + r) * 2 + 1] = a2;
+        }
       }
     }
     __syncthreads();
     if (tid < NT * 32) {
       const int n = nt0 * 32 + tid;
       if (n < p.N) {
-        float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < 4; ++wv) {
-          t1 += red[(wv * NT * 32 + tid) * 2];
-          t2 += red[(wv * NT * 32 + tid) * 2 + 1];
+        for (int it = 0; it < NI; ++it) {
+          float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+          for (int wv = 0; wv < 4; ++wv) {
+            t1 += red[((it * 4 + wv) * NT * 32 + tid) * 2];
+            t2 += red[((it * 4 + wv) * NT * 32 + tid) * 2 + 1];
+          }
+          atomicAdd(&p.in_acc[((size_t)(b + it) * p.N + n) * 2], (double)t1);
+          atomicAdd(&p.in_acc[((size_t)(b + it) * p.N + n) * 2 + 1], (double)t2);
         }
-        atomicAdd(&p.in_acc[((size_t)b * p.N + n) * 2], (double)t1);
-        atomicAdd(&p.in_acc[((size_t)b * p.N + n) * 2 + 1], (double)t2);
       }
     }
     __syncthreads();  // red is inside the region the staging tiles of other waves do not touch, but keep phases apart
@@ -509,12 +527,12 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3) ? 3 : 2) void conv3_halo
         const int row = vv >> 2, cv = vv & 3;
         int hh, ww;
         halo_row_to_hw(row, hh, ww);
-        const int gh = h0 + 4 * i + hh, gw = w0 + ww;
+        const int gh = h0 + (BP ? 0 : 4 * i) + hh, gw = w0 + ww;
         const int n = (nt0 + j) * 32 + cv * 8;
         if (gd < p.D && gh < p.H && gw < p.W && n < p.N) {
           float xv[8];
           load8(&stage[row * STAGE_LD + cv * 8], xv);
-          const size_t m = (((size_t)b * p.D + gd) * p.H + gh) * p.W + gw;
+          const size_t m = (((size_t)(b + (BP ? i : 0)) * p.D + gd) * p.H + gh) * p.W + gw;
           if (p.part) store8(p.part + ((size_t)blockIdx.z * p.B * p.D * p.H * p.W + m) * (p.ntn * 32) + n, xv);
           else if (p.n_split > 0 && n >= p.n_split) {
             if (p.residual2) {
@@ -599,9 +617,14 @@ template <> struct HaloDma<bf16> {
     const int64_t vox = (int64_t)p.B * p.D * p.H * p.W;
     const int cmax = p.C1 > p.C2 ? p.C1 : p.C2;
     if (vox * cmax >= (1ll << 31)) return false;
-    const int bricks = p.B * p.nbd * p.nbh * p.nbw;
     const int ntn = p.ntn;
     const int NT = ntn % 4 == 0 ? 4 : (ntn % 2 == 0 ? 2 : 1);
+    // batch-pair bricks (see the kernel): fewer bricks when the height leaves an 8-row brick at most half full (12 rows: 3 bricks
+    // of 4 for two items against 2 x 2 of 8); four n tiles only (the shapes that have it: 128 .. 512 channels at 12 x 12 x 24)
+    const int nbh4 = (p.H + 3) / 4;
+    const bool bp = NT == 4 && p.B % 2 == 0 && (p.B / 2) * nbh4 < p.B * p.nbh && !(ctu_option_route() & CTU_ROUTE_HALO_NO_BATCH_PAIR) &&
+                    !(ctu_option_nt_debug() & 16);   // (the diagnostic STAMP build has no batch-pair variant)
+    const int bricks = bp ? (p.B / 2) * p.nbd * nbh4 * p.nbw : p.B * p.nbd * p.nbh * p.nbw;
     // Small volumes (the 12x12x24 and 6x6x12 stages: 27 and 4 bricks) leave most CUs idle: split the input channels
     // over workgroups, keep fp32 partial outputs in the workspace and sum them in a second pass (no atomics).
     const int HCT = (p.C1 + p.C2) / 16;
@@ -621,6 +644,7 @@ template <> struct HaloDma<bf16> {
       if (ksplit < 2) ksplit = 1;
     }
     HaloArgs q = p;
+    if (bp) q.nbh = nbh4;
     q.debug = ctu_option_nt_debug();
     q.hc_per_split = (HCT + ksplit - 1) / ksplit;
     ksplit = (HCT + q.hc_per_split - 1) / q.hc_per_split;
@@ -638,7 +662,8 @@ template <> struct HaloDma<bf16> {
     // CTU_ROUTE_HALO_THIN: a few KiB of unused dynamic LDS push the third (NT <= 2) / second (NT = 4) resident workgroup
     // off the CU - its registers, wave slots and LDS are then free for kernels of other streams
     const size_t thin = (ctu_option_route() & CTU_ROUTE_HALO_THIN) ? (NT == 4 ? 12 * 1024 : 4 * 1024) : 0;
-    if (NT == 4 && alone) hipLaunchKernelGGL((conv3_halo_dma_kernel<4, 3, 3, false, 0>), grid, dim3(256), thin, s, q);
+    if (bp) hipLaunchKernelGGL((conv3_halo_dma_kernel<4, 2, 3, false, 4, true>), grid, dim3(256), 0, s, q);   // (two-stage ring: 70 KiB, two workgroups per CU)
+    else if (NT == 4 && alone) hipLaunchKernelGGL((conv3_halo_dma_kernel<4, 3, 3, false, 0>), grid, dim3(256), thin, s, q);
     else if (NT == 4) hipLaunchKernelGGL(conv3_halo_dma_kernel<4>, grid, dim3(256), thin, s, q);
     else if (NT == 2 && long_stages) hipLaunchKernelGGL((conv3_halo_dma_kernel<2, 2, 9, false, 0>), grid, dim3(256), thin, s, q);
     else if (NT == 2 && alone) hipLaunchKernelGGL((conv3_halo_dma_kernel<2, 2, 3, false, 0>), grid, dim3(256), thin, s, q);

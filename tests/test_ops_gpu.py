@@ -145,6 +145,9 @@ CONV_CASES = [  # B, D,H,W, C1, C2, N, k, s, p
     (1, 12, 12, 24, 96, 0, 32, 3, 1, 1),  # halo kernel: NT=1, three chunks
     (1, 5, 16, 8, 64, 64, 160, 3, 1, 1),  # halo kernel: N=160 -> 5 n tiles (NT=1 path), concat
     (1, 8, 8, 16, 256, 0, 256, 3, 1, 1),  # halo kernel: 8 n tiles -> two n blocks, 16 half chunks, several bricks/workgroup
+    (2, 12, 12, 24, 128, 0, 128, 3, 1, 1),  # halo kernel: batch-pair bricks (12 rows: 3 x 4 for two items), channel split + finish pass
+    (2, 5, 12, 9, 64, 64, 128, 3, 1, 1),    # batch-pair bricks, ragged d and w, concat forward + split data gradient
+    (4, 4, 4, 8, 32, 0, 256, 3, 1, 1),      # batch-pair bricks, two pairs, two n blocks of four tiles
 ]
 
 
@@ -180,7 +183,8 @@ def test_conv3d(ops, dtype, case, halo):
 
 
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("case", [(2, 7, 9, 17, 32, 32, 64), (1, 8, 8, 16, 64, 0, 160), (2, 4, 8, 8, 32, 0, 32)])
+@pytest.mark.parametrize("case", [(2, 7, 9, 17, 32, 32, 64), (1, 8, 8, 16, 64, 0, 160), (2, 4, 8, 8, 32, 0, 32),
+                                  (2, 12, 12, 24, 128, 0, 128), (2, 5, 12, 9, 64, 64, 128)])   # (the last two: batch-pair bricks, sums per item)
 def test_conv_instance_norm_fused_statistics(ops, case, fused):
     """bf16 conv3x3x3 -> InstanceNorm -> LeakyReLU: the statistics come from the conv epilogue (fp32 accumulators summed per
     brick, ctu_conv3_halo in_acc + ctu_in_finalize) or, with fused=False, from the separate pass over the bf16 output.
