@@ -51,7 +51,9 @@ const char* ctu_last_error(void);
  * routing switches for measurements (1: short-K layers on the general NT kernel instead of gemm_nt_stream, 2: no 128-deep
  * stages, 4: no two-k-group trunk tiles, 8: previous channel-split rule of the small 3x3x3 convs, 16: 9-tap weight stages
  * in the halo kernels, 32: wave 0 gathers the halo alone, 64: weight-gradient operand DMA in one burst, 128: weight-gradient
- * atomics even with a workspace); "nt_debug" = bits
+ * atomics even with a workspace, 256: 32-KiB LDS reduction in every InstanceNorm backward reduce, 512: one resident halo
+ * workgroup fewer per CU, 1024: at least 64 rows per workgroup in every InstanceNorm reduction, 2048: no batch-pair bricks
+ * in the halo forward / data-gradient kernels - each bit restores a previous rule); "nt_debug" = bits
  * that switch a kernel's memory traffic off for timing.  Options are plain process-wide ints read per launch - no
  * launch path calls getenv. */
 int ctu_set_option(const char* name, int32_t value);
