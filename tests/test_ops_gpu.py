@@ -591,7 +591,8 @@ def test_batched_fragment_packing_equals_single(ops):
             assert torch.equal(ta, tb)
 
 
-@pytest.mark.parametrize("case", [(2, 8, 16, 16, 32, 32), (1, 5, 9, 11, 64, 96), (2, 4, 8, 8, 128, 64)])
+@pytest.mark.parametrize("case", [(2, 8, 16, 16, 32, 32), (1, 5, 9, 11, 64, 96), (2, 4, 8, 8, 128, 64),
+                                  (2, 12, 12, 24, 128, 128)])   # (the last: batch-pair bricks reading the blocked layout)
 def test_b16_layout_chain_equals_channels_last(ops, case):
     """CTU_LAYOUT_B16 (the 16-channel-blocked tensor between an InstanceNorm and the 3x3x3 halo convolution behind it, and
     between an InstanceNorm backward and the convolution in front of it) changes where bytes live, not what is computed:
