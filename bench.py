@@ -24,6 +24,13 @@ import os
 import sys
 import time
 
+# Before HIP initialises (ROCclr reads it once): eight hardware queues instead of the default four.  The step runs on five to six
+# HIP streams (two encoder branches, weight-gradient companions, the gradient-exchange stream); RCCL's communicator adds its own,
+# and with four queues two of OUR streams then share one: 47.5 -> 55.4 ms per step from nothing but dist.init_process_group("nccl")
+# (profiles/r03_bench_rccl_group_vs_hw_queues.log; 5, 6 and 8 queues: 47.3 - 47.5 with and without the group).  A value the caller
+# has set stays.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 import torch.distributed as dist
 
@@ -200,6 +207,9 @@ def main():
     ap.add_argument("--no-opt-overlap", dest="opt_overlap", action="store_false", help="one AdamW launch after backward()")
     ap.add_argument("--enc0-stream", action="store_true",
                     help="A/B: vit_encoder0 on a third HIP stream from the start of the forward pass (measured slower: off)")
+    ap.add_argument("--wgrad-stream", action="store_true",
+                    help="weight-gradient kernels on companion HIP streams (ops.WGRAD_STREAM; off by default: no gain with launch "
+                         "lists and one more pair of streams for the stream-to-queue mapping to get wrong)")
     ap.add_argument("--route", type=int, default=0,
                     help="A/B measurements: ctu_set_option(\"route\", N) bit set (include/ctunet_hip.h); 0 = the shipped routing")
     ap.add_argument("--serial", action="store_true",
@@ -220,7 +230,15 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # CTU_BENCH_FORCE_DP=1 (one-GPU boxes): a one-rank RCCL process group and the DataParallel wrapper at N = 1 - every bucket goes
+    # through ncclAllReduce on the side stream, so RCCL's communicator, its streams and the bucket schedule are in the step
+    force_mode = os.environ.get("CTU_BENCH_FORCE_DP", "") if world == 1 else ""   # "1": group + wrapper; "pg": group only; "dp": wrapper only
+    force_dp = force_mode in ("1", "dp")
+    force_pg = force_mode in ("1", "pg")
+    if force_pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or force_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
@@ -241,11 +259,11 @@ def main():
     # static_unused: the parameters without a gradient in the first (warm-up) step never get one (seven ResBlock.conv3 that the
     # models build and never call); their buckets then go out during backward instead of behind it (train.DataParallel)
     comm = None
-    if world > 1 and a.payload == "bf16":
+    if (world > 1 or force_dp) and a.payload == "bf16":
         from hybrid_ctunet_amd.comm import Communicator
         comm = Communicator.from_torch()
     dp = H.DataParallel(model, flat=flat, bucket_mb=a.bucket_mb, static_unused=a.warmup > 0, payload=a.payload,
-                        comm=comm) if world > 1 else None
+                        comm=comm) if (world > 1 or force_dp) else None
     use_graph = world == 1 and a.graph and not a.serial
     # the optimizer updates a bucket of parameters as soon as its gradients are final (behind the bucket's all-reduce for N > 1):
     # same arithmetic as one update after backward(), queued under the rest of the backward pass (train.FusedAdamW)
@@ -266,7 +284,7 @@ def main():
         """Serial = every kernel on one stream.  The timed region overlaps the two encoder branches and the weight-gradient
         kernels on companion streams; the per-kernel roofline figures are taken with the overlap off, so a launch's HIP
         events bracket that kernel alone."""
-        _ops.WGRAD_STREAM = not flag
+        _ops.WGRAD_STREAM = bool(a.wgrad_stream) and not flag   # (companion streams of the weight-gradient kernels: off, the library default)
         opt.overlap_enabled = not flag
         if hasattr(model, "overlap_branches"):
             model.overlap_branches = not flag

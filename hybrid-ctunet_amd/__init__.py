@@ -8,7 +8,15 @@ through the shim module at the repository root, which registers this directory u
 Nothing here falls back to eager PyTorch or to the CPU: the kernels live in csrc/libctunet_hip.so (built by
 ``__graft_entry__.build()``), and every op raises if that library or a HIP device is missing.
 """
-from .networks.hybrid_CTUNet import CTUNet, CUNet, TUNet  # noqa: F401
+import os as _os
+
+# The training step runs on five to six HIP streams (two encoder branches, weight-gradient companions, the gradient-exchange
+# stream) and RCCL adds its own.  ROCclr maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two of the step's
+# streams sharing one queue cost 8 ms of a 47 ms step (bench.py, profiles/r03_bench_rccl_group_vs_hw_queues.log).  Read once when
+# HIP initialises, so this only helps when the package is imported before the first GPU call; a value the caller set stays.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from .networks.hybrid_CTUNet import CTUNet, CUNet, TUNet  # noqa: F401,E402
 from .train import (DataParallel, FlatParams, FusedAdamW, GraphedStep, LOSSES, ctunet_loss, cunet_loss, dice_ce_loss,  # noqa: F401
                     gradient_ready_order, tunet_loss)
 from .inference import dice_per_organ, hybrid_complement, sliding_window_inference  # noqa: F401
