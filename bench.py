@@ -207,9 +207,9 @@ def main():
     ap.add_argument("--no-opt-overlap", dest="opt_overlap", action="store_false", help="one AdamW launch after backward()")
     ap.add_argument("--enc0-stream", action="store_true",
                     help="A/B: vit_encoder0 on a third HIP stream from the start of the forward pass (measured slower: off)")
-    ap.add_argument("--wgrad-stream", action="store_true",
-                    help="weight-gradient kernels on companion HIP streams (ops.WGRAD_STREAM; off by default: no gain with launch "
-                         "lists and one more pair of streams for the stream-to-queue mapping to get wrong)")
+    ap.add_argument("--wgrad-stream", action=argparse.BooleanOptionalAction, default=True,
+                    help="weight-gradient kernels on companion HIP streams (ops.WGRAD_STREAM, the library default; "
+                         "--no-wgrad-stream: A/B, +1.0 - 1.5 ms per step)")
     ap.add_argument("--route", type=int, default=0,
                     help="A/B measurements: ctu_set_option(\"route\", N) bit set (include/ctunet_hip.h); 0 = the shipped routing")
     ap.add_argument("--serial", action="store_true",
@@ -284,7 +284,7 @@ def main():
         """Serial = every kernel on one stream.  The timed region overlaps the two encoder branches and the weight-gradient
         kernels on companion streams; the per-kernel roofline figures are taken with the overlap off, so a launch's HIP
         events bracket that kernel alone."""
-        _ops.WGRAD_STREAM = bool(a.wgrad_stream) and not flag   # (companion streams of the weight-gradient kernels: off, the library default)
+        _ops.WGRAD_STREAM = bool(a.wgrad_stream) and not flag   # (companion streams of the weight-gradient kernels: the library default is on)
         opt.overlap_enabled = not flag
         if hasattr(model, "overlap_branches"):
             model.overlap_branches = not flag

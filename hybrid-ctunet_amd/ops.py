@@ -65,13 +65,13 @@ def side_streams(device):
 # waits for: with a training harness that owns the gradient storage (direct sinks) they are queued on a companion stream
 # of the layer's compute stream and overlap the data-gradient chain - the small-volume stages and the 864-token ViT
 # trunk are launch-latency bound, two kernels side by side fill what one leaves idle.  The optimizer joins the streams.
-# Round 3: OFF by default.  With the launch lists the host no longer paces the backward pass and the companion streams buy nothing
-# (46.86 vs 46.89 ms per step); what they do add is a dependence on how HIP maps streams to its hardware queues: with
-# GPU_MAX_HW_QUEUES >= 5 every stream gets a queue of its own, the HBM-bound per-bucket optimizer updates and the weight-gradient
-# kernels then run truly beside the backward pass, and the step takes 66 - 67 ms instead of 47 (profiles/r03_bench_hw_queues_sweep.log;
-# co-residency of matrix-bound and memory-bound kernels is what this chip does worst).  CTU_WGRAD_STREAM=1
-# switches them back on.
-WGRAD_STREAM = bool(os.environ.get("CTU_WGRAD_STREAM")) and not os.environ.get("CTU_NO_WGRAD_STREAM")
+# Round 3: on (CTU_NO_WGRAD_STREAM=1 switches them off).  Same box, python bench.py --steps 20 --warmup 5: 45.86 / 45.86 ms per step
+# with the companion streams, 46.89 / 46.84 without at four hardware queues; 46.8 - 47.0 against 48.3 at eight, with or without
+# an RCCL communicator in the process (profiles/r03_bench_rccl_group_vs_hw_queues.log).  (An earlier "46.86 vs 46.89, no gain" in
+# the history of this comment compared two runs of a bench.py that switched them on in both.)  What made the step fragile against
+# the stream-to-queue mapping was the optimizer's OWN update stream (66 ms with >= 5 queues, profiles/r03_bench_hw_queues_sweep.log),
+# which is gone: the per-bucket updates ride on the branch stream.
+WGRAD_STREAM = not os.environ.get("CTU_NO_WGRAD_STREAM")
 
 
 class _WgradSide:
