@@ -207,9 +207,10 @@ def main():
     ap.add_argument("--no-opt-overlap", dest="opt_overlap", action="store_false", help="one AdamW launch after backward()")
     ap.add_argument("--enc0-stream", action="store_true",
                     help="A/B: vit_encoder0 on a third HIP stream from the start of the forward pass (measured slower: off)")
-    ap.add_argument("--wgrad-stream", action=argparse.BooleanOptionalAction, default=True,
-                    help="weight-gradient kernels on companion HIP streams (ops.WGRAD_STREAM, the library default; "
-                         "--no-wgrad-stream: A/B, +1.0 - 1.5 ms per step)")
+    ap.add_argument("--wgrad-stream", action=argparse.BooleanOptionalAction, default=None,
+                    help="weight-gradient kernels on companion HIP streams (ops.WGRAD_STREAM).  Default: on at N = 1 (-1.0 to "
+                         "-1.5 ms per step), off under data parallelism (train.DataParallel switches them off: with them every "
+                         "bucket's event fence costs ~1 ms, profiles/r03_bench_dp_rehearsal_world1.log)")
     ap.add_argument("--route", type=int, default=0,
                     help="A/B measurements: ctu_set_option(\"route\", N) bit set (include/ctunet_hip.h); 0 = the shipped routing")
     ap.add_argument("--serial", action="store_true",
@@ -284,7 +285,8 @@ def main():
         """Serial = every kernel on one stream.  The timed region overlaps the two encoder branches and the weight-gradient
         kernels on companion streams; the per-kernel roofline figures are taken with the overlap off, so a launch's HIP
         events bracket that kernel alone."""
-        _ops.WGRAD_STREAM = bool(a.wgrad_stream) and not flag   # (companion streams of the weight-gradient kernels: the library default is on)
+        wg = a.wgrad_stream if a.wgrad_stream is not None else dp is None
+        _ops.WGRAD_STREAM = bool(wg) and not flag   # (companion streams of the weight-gradient kernels)
         opt.overlap_enabled = not flag
         if hasattr(model, "overlap_branches"):
             model.overlap_branches = not flag

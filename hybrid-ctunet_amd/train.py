@@ -4,6 +4,7 @@ wrapper that all-reduces gradient buckets over RCCL on a side stream while backw
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -565,6 +566,9 @@ class DataParallel(nn.Module):
         if payload == "bf16" and comm is None:
             raise ValueError("payload='bf16' needs a comm.Communicator (hybrid_ctunet_amd.comm.Communicator.from_torch())")
         self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
+        # rehearsal on a one-GPU box (bench.py CTU_BENCH_FORCE_DP=1 CTU_DP_REDUCE_AT_WORLD1=1): run every bucket's collective at
+        # world 1 as well, so that the event fences, RCCL's stream and finish() carry the real choreography
+        self._alone = self.world == 1 and dist.is_initialized() and bool(os.environ.get("CTU_DP_REDUCE_AT_WORLD1"))
         params = list(ready_order) if ready_order is not None else [p for p in module.parameters() if p.requires_grad]
         if flat is None:
             flat = FlatParams.of(params) or FlatParams(params)
@@ -588,6 +592,12 @@ class DataParallel(nn.Module):
         self._launched = [False] * len(self.buckets)
         self._works = []
         self._is_cuda = f.flat.is_cuda
+        if (self.world > 1 or self._alone) and self._is_cuda and not os.environ.get("CTU_WGRAD_STREAM"):
+            # Measured with that rehearsal: one `side.wait_event(bucket event)` per bucket - the fence every bucket needs - costs
+            # 20 ms per step while the weight-gradient companion streams are in use (65 ms against 46; 47.8 with the companion
+            # streams off; the collective itself, the record and the stream count are not it: profiles/
+            # r03_bench_dp_rehearsal_world1.log).  Under data parallelism the weight gradients therefore stay on their layer's stream.
+            ops.WGRAD_STREAM = False
         self._side = torch.cuda.Stream() if self._is_cuda else None
         self._seen = [False] * len(f.params)
         self._opt = None
@@ -630,7 +640,7 @@ class DataParallel(nn.Module):
             self._launch(b)
 
     def _launch(self, b):
-        if self._launched[b] or self.world == 1:
+        if self._launched[b] or (self.world == 1 and not self._alone):
             self._launched[b] = True
             return
         self._launched[b] = True
@@ -698,7 +708,7 @@ class DataParallel(nn.Module):
         for w in self._works:
             w.wait()
         self._works = []
-        if self._is_cuda and self.world > 1:
+        if self._is_cuda and (self.world > 1 or self._alone):
             cur = torch.cuda.current_stream()
             if self.exposed is not None:   # measurement: how long the compute stream stands waiting for the exchange
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
