@@ -450,6 +450,7 @@ def main():
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
