@@ -443,7 +443,10 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3 && !BP) ? 3 : 2) void con
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            CTU_MFMA_YIELD_HERE
+          }
       }
     }
     if (++s == SPC) { s = 0; ++hc; }
@@ -1242,10 +1245,13 @@ static int halo_wgrad_impl(ctu_dtype dtype, const void* dy, const void* x1, cons
     const int tiles = p.tiles_n * p.tiles_c;
     int splits = (256 + tiles - 1) / tiles;
     if (splits > p.nbricks) splits = p.nbricks;
+    const int64_t panel = (int64_t)27 * N * (C1 + C2);
+    // the parameter-layout form has no atomics fallback: fewer, longer brick ranges when the partial panels of the preferred
+    // split count do not fit the workspace (tile counts that are not powers of two: N = 512, K = 768 -> 192 tiles x 2 splits)
+    if (param_layout && ws && (int64_t)splits * panel > ws_floats && panel <= ws_floats) splits = (int)(ws_floats / panel);
     p.bricks_per_block = (p.nbricks + splits - 1) / splits;
     splits = (p.nbricks + p.bricks_per_block - 1) / p.bricks_per_block;
     CTU_REQUIRE((int64_t)tiles * splits < (1ll << 31), "conv3_halo_wgrad: too many workgroups");
-    const int64_t panel = (int64_t)27 * N * (C1 + C2);
     const bool partials = param_layout ||
                           (splits > 1 && ws && (int64_t)splits * panel <= ws_floats && (C1 + C2) % 4 == 0 &&
                            !(ctu_option_route() & CTU_ROUTE_HALO_WGRAD_ATOMICS));

@@ -1,5 +1,17 @@
 // MFMA fragment helpers shared by the implicit-GEMM kernels (gfx950).
 #pragma once
+// Measurement build only (tools/build_variant.sh): -DCTU_MFMA_YIELD=n puts `s_nop n-1` behind every bf16 MFMA of the halo kernels.
+// A wave whose next instruction is an MFMA waiting for the matrix pipe keeps every other wave of its SIMD from issuing
+// (profiles/r04_corun_mechanism.log); the nop completes long before the pipe is free again and leaves those cycles to the others.
+#ifndef CTU_MFMA_YIELD
+#define CTU_MFMA_YIELD 0
+#endif
+#if CTU_MFMA_YIELD
+#define CTU_MFMA_YIELD_HERE asm volatile("s_nop %0" ::"n"(CTU_MFMA_YIELD - 1));
+#else
+#define CTU_MFMA_YIELD_HERE
+#endif
+
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------------------
@@ -53,6 +65,7 @@ template <> struct Mma<bf16> {
   static __device__ __forceinline__ Frag gather_perm(const bf16* p, int stride) { return gather2(p, stride, 8); }
   static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    CTU_MFMA_YIELD_HERE
   }
 };
 

@@ -78,6 +78,9 @@ class _WS:
 
 
 _FWS: Dict[tuple, _WS] = {}
+# (mean, rstd) tables of a plan sit 32 KiB apart and the fp64 accumulators hold 1 << 14 entries: a block whose widest norm has
+# more than 8192 / 2 (batch item, channel) pairs takes the per-op path, whose workspaces grow on demand (bottleneck_ok, resblock_ok)
+STATS_MAX = 8192
 
 
 def _fws(device, sid) -> _WS:
@@ -190,7 +193,8 @@ class _InFwd:
                other, clear_n)
         self.k += 1
         self.prev = B * C * 2
-        assert self.prev <= (1 << 14)
+        if self.prev > STATS_MAX:
+            raise RuntimeError(f"fused path: {B} x {C} InstanceNorm statistics exceed the fixed tables (the *_ok guards route such shapes to the per-op path)")
 
 
 class _InBwd:
@@ -207,7 +211,8 @@ class _InBwd:
         R.call("ctu_in_bwd_apply", BF16, gy, x, y, stats, sums, gx, gres, B, S, C, int(act), clear, clear_n, int(dx_b16), mask)
         self.k += 1
         self.prev = B * C * 2
-        assert self.prev <= (1 << 14)
+        if self.prev > STATS_MAX:
+            raise RuntimeError(f"fused path: {B} x {C} InstanceNorm statistics exceed the fixed tables (the *_ok guards route such shapes to the per-op path)")
 
 
 class ConvSpec:
@@ -514,7 +519,8 @@ class _BneckPlan:
             G.add("gd", Mo * N4 * 2), G.add("gxd", (Mo if self.cd.dgrad_via == "gemm_s2" else Mi) * Cin * 2)
         if self.c2.dgrad_via == "halo_up2":
             G.add("up2", Mi * P * 2)       # conv2's dY zero-upsampled to its input's size
-        assert B * N4 * 2 <= 8192
+        if B * N4 * 2 > STATS_MAX:
+            raise RuntimeError("fused Bottleneck: statistics tables too small for this batch x width (bottleneck_ok guards this)")
         self.need = _Need()
         self.fwd = None
         self.bwd: Dict[tuple, object] = {}
@@ -668,7 +674,7 @@ def bottleneck_ok(blk, x) -> bool:
     if not usable(x) or x.dim() != 5:
         return False
     Cin, P = x.shape[-1], blk.conv1.out_channels
-    return Cin % 32 == 0 and P % 32 == 0 and x.numel() < (1 << 31)
+    return Cin % 32 == 0 and P % 32 == 0 and x.numel() < (1 << 31) and x.shape[0] * 4 * P * 2 <= STATS_MAX
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -896,15 +902,15 @@ class PipeFn(torch.autograd.Function):
         vals = [x.data_ptr(), out.data_ptr()] + pv + [ops._splitk_workspace(dev, pl.need.skws).data_ptr()] + \
                [t.data_ptr() for t in bufs]
         pl.fwd.run(vals, (sid,))
-        ctx.pl, ctx.bufs, ctx.out = pl, bufs, out
-        ctx.save_for_backward(x, *params)
+        ctx.pl, ctx.bufs = pl, bufs
+        ctx.save_for_backward(x, out, *params)
         for i, p in enumerate(params):
             ops.sink_expect(p, ctx.needs_input_grad[3 + i])
         return out
 
     @staticmethod
     def backward(ctx, gy):
-        x, *params = ctx.saved_tensors
+        x, out, *params = ctx.saved_tensors
         pl, bufs = ctx.pl, ctx.bufs
         gy = gy.contiguous()
         dev = x.device
@@ -923,15 +929,15 @@ class PipeFn(torch.autograd.Function):
         key1 = (dev, run.s1, ops._ws_epoch)
         vals = [x.data_ptr(), gy.data_ptr(), gx.data_ptr()] + pv + tv + [t[0].data_ptr() for t in targets] + \
                [ops._splitk_workspace(dev, pl.need.skws).data_ptr(), _tn_ws_for(key1).data_ptr(), _lnws(dev, run.s0).data_ptr()] + \
-               [t.data_ptr() for t in bufs] + [ctx.out.data_ptr()] + [t.data_ptr() for t in G]
-        run.keep_alive(x, gy, ctx.out, *bufs, *G)
+               [t.data_ptr() for t in bufs] + [out.data_ptr()] + [t.data_ptr() for t in G]
+        run.keep_alive(x, gy, out, *bufs, *G)
         plan.run(vals, (run.s0, run.s1))
         # "gradient complete", last layer first (the flat gradient buffer's order); main-stream and weight-gradient-stream
         # gradients alike: whoever listens joins the side streams
         for t in reversed(targets):
             if t[1] is not None:
                 t[1]()
-        ctx.bufs = ctx.out = None
+        ctx.bufs = None
         return (gx, None, None) + tuple(t[2] for t in targets)
 
 
@@ -967,7 +973,13 @@ def _all_trainable(module) -> bool:
 def vit_trunk_ok(vit, x) -> bool:
     b0 = vit.transformer[0]
     drop = max(b0.attn.dropout.p, b0.attn.to_out[1].p, b0.ff.net[3].p, b0.ff.net[5].p)
-    return usable(x) and x.dim() == 3 and not (vit.training and drop > 0.0) and _all_trainable(vit.transformer)
+    if not (usable(x) and x.dim() == 3 and not (vit.training and drop > 0.0) and _all_trainable(vit.transformer)):
+        return False
+    # AttnRes sizes qkv / o and their GEMMs from `dim`: heads * dim_head has to equal it (num_heads is a reference CLI flag,
+    # main_CTUNet.py:59; hidden_size 768 with 8 heads of 64 gives an inner width of 512 - the per-op path is shape-generic)
+    dim = x.shape[-1]
+    return all(tuple(b.attn.to_qkv.weight.shape) == (3 * dim, dim) and tuple(b.attn.to_out[0].weight.shape) == (dim, dim)
+               for b in vit.transformer)
 
 
 def vit_trunk(blocks, x):
@@ -997,11 +1009,14 @@ def up_stage_ok(x, blk, ind, training) -> bool:
     if not (usable(x) and x.dim() == 5):
         return False
     mods = (blk[1], blk[2], blk[5], blk[6]) if ind <= 2 else (blk[1], blk[2])
+    C = x.shape[-1]
     for m in mods:
         f = m.fn
         p = (f.to_out[1].p if hasattr(f, "to_out") else max(f.net[3].p, f.net[5].p))
         if training and p > 0.0:
             return False
+        if hasattr(f, "to_qkv") and (tuple(f.to_qkv.weight.shape) != (3 * C, C) or tuple(f.to_out[0].weight.shape) != (C, C)):
+            return False   # (inner width != dim: AttnRes sizes its buffers from dim)
     return _all_trainable(blk)
 
 
@@ -1067,7 +1082,8 @@ class _ResBlockPlan:
             G.add("g3", M * N * 2), G.add("gs1", M * C1 * 2)
             if C2:
                 G.add("gs2", M * C2 * 2)
-        assert B * N * 2 <= 8192
+        if B * N * 2 > STATS_MAX:
+            raise RuntimeError("fused ResBlock: statistics tables too small for this batch x width (resblock_ok guards this)")
         self.need = _Need()
         self.fwd = None
         self.bwd: Dict[tuple, object] = {}
@@ -1215,7 +1231,7 @@ def resblock_ok(blk, x1, x2, grad_stash) -> bool:
     if c1.kernel_size != (3, 3, 3) or c1.stride != (1, 1, 1) or blk.conv2.kernel_size != (3, 3, 3):
         return False
     C1, C2, N = x1.shape[-1], (x2.shape[-1] if x2 is not None else 0), c1.out_channels
-    if C1 % 32 or C2 % 32 or N % 32 or x1.numel() // C1 * max(C1, C2, N) >= (1 << 31):
+    if C1 % 32 or C2 % 32 or N % 32 or x1.numel() // C1 * max(C1, C2, N) >= (1 << 31) or x1.shape[0] * N * 2 > STATS_MAX:
         return False
     if not blk.downsample and (grad_stash is not None or x2 is not None):
         return False

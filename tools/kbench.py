@@ -7,6 +7,8 @@ import time
 
 import torch
 
+import _variant  # noqa: F401  (CTU_LIB_VARIANT=TAG: a measurement build of the library)
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hybrid_ctunet_amd  # noqa: E402,F401
 from hybrid_ctunet_amd import ops  # noqa: E402
