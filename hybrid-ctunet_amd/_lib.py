@@ -62,6 +62,7 @@ _SIGS = {
     "ctu_in_apply": [_i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp],
     "ctu_in_bwd_reduce": [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp],
     "ctu_in_bwd_apply": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _vp],
+    "ctu_in_bwd_fused": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp],
     "ctu_layernorm_fwd": [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "ctu_layernorm_bwd": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "ctu_layernorm_bwd_add": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
@@ -100,7 +101,7 @@ _SIGS = {
     "ctu_plan_run": [_vp, C.POINTER(C.c_uint64), _i32, C.POINTER(_vp), _i32],
     "ctu_plan_destroy": [_vp],
 }
-EXPORTED = sorted(list(_SIGS) + ["ctu_abi_version", "ctu_last_error", "ctu_allreduce_scratch_bytes"])
+EXPORTED = sorted(list(_SIGS) + ["ctu_abi_version", "ctu_last_error", "ctu_allreduce_scratch_bytes", "ctu_sync_timeouts"])
 
 _lib = None
 
@@ -143,7 +144,8 @@ def lib():
         L.ctu_allreduce_scratch_bytes.argtypes = [_i32, _i64]
         L.ctu_allreduce_scratch_bytes.restype = _i64
         L.ctu_last_error.restype = C.c_char_p
-        if L.ctu_abi_version() != 6:
+        L.ctu_sync_timeouts.restype = C.c_int
+        if L.ctu_abi_version() != 7:
             raise RuntimeError("libctunet_hip.so ABI version mismatch")
         _lib = L
     return _lib

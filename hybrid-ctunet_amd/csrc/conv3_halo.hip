@@ -565,6 +565,221 @@ __global__ __launch_bounds__(256, (RD == 2 && TPS == 3 && !BP) ? 3 : 2) void con
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// N-split variant (round 4; four n tiles = 128 output channels per workgroup): wave w owns n tile w for ALL 256 voxels of the
+// brick (8 M tiles) instead of a d slice for all n tiles.  What that buys: the weights a wave needs are its own - fetched by
+// LDS-DMA into a WAVE-PRIVATE ring (PF fragments of 1 KiB, one per tap, PF - 1 taps ahead), waited for with a counted vmcnt and
+// read back by the same wave, so no other wave is involved: the workgroup barrier per weight stage (every 6 NT MFMAs per
+// wave; 26 - 32 % of the kernel waiting there) is gone, one barrier per 16-channel half chunk remains
+// (216 MFMAs per wave) for the shared halo image.  What it costs: every wave reads the whole halo image (8 A fragments per tap
+// instead of 2: 9 KiB of LDS reads per 8 MFMAs instead of 6), and 128 accumulator registers per lane.
+// Same HaloArgs, same fragment-order panel, same halo image and swizzle, same epilogue forms as conv3_halo_dma_kernel.
+// ---------------------------------------------------------------------------------------------------------
+template <int PF>
+__global__ __launch_bounds__(256, 2) void conv3_halo_ns_kernel(const HaloArgs p) {
+  constexpr int HVOX = HALO_D * HALO_H * HALO_W;      // 600
+  constexpr int HINS = (2 * HVOX + 63) / 64;          // 19 DMA wave-instructions per halo half chunk
+  constexpr int HBUF = HINS * 1024;
+  constexpr int HPW = (HINS + 3) / 4;                 // gather pieces per wave: 5, 5, 5, 4
+  constexpr int RING0 = 2 * HBUF;
+  constexpr int STAGE_LD = 32 + 4;
+  constexpr int LDS_MAIN = RING0 + 4 * PF * 1024;
+  constexpr int LDS_EPI = 4 * 32 * STAGE_LD * 4;
+  constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+  static_assert(27 % PF == 0 || PF > 27, "ring slots must repeat per half chunk");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int bw = t % p.nbw; t /= p.nbw;
+  const int bh = t % p.nbh; t /= p.nbh;
+  const int bd = t % p.nbd;
+  const int b = t / p.nbd;
+  const int d0 = bd * HB_D, h0 = bh * HB_H, w0 = bw * HB_W;
+  const int nt = blockIdx.y * 4 + wave;                              // this wave's n tile
+  const int hc_b = blockIdx.z * p.hc_per_split;
+  const int HC = min((p.C1 + p.C2) / 16, hc_b + p.hc_per_split);    // (exclusive end)
+  const bf16* x1 = reinterpret_cast<const bf16*>(p.x1);
+  const bf16* x2 = reinterpret_cast<const bf16*>(p.x2);
+  const bf16* wf = reinterpret_cast<const bf16*>(p.wfrag);
+
+  // per-lane halo sources of this wave's gather pieces (piece k fills slots 64 k ..): as in conv3_halo_dma_kernel
+  // (a wave whose share is one piece short repeats its last piece: every wave issues HPW instructions, static vmcnt counts)
+  int hm[HPW], hdst[HPW];
+  unsigned hpart = 0;
+#pragma unroll
+  for (int k = 0; k < HPW; ++k) {
+    const int piece = min(wave * HPW + k, HINS - 1);
+    const int S = piece * 64 + lane;
+    int m = -1;
+    if (S < 2 * HVOX) {
+      const int vox = S >> 1, hs = S & 1;
+      const int R = vox / HALO_W, hw = vox - R * HALO_W;
+      const int hd = R / HALO_H, hh = R - hd * HALO_H;
+      const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+      hpart |= (unsigned)(hs ^ ((R >> 1) & 1)) << k;
+      if ((unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W)
+        m = ((b * p.D + gd) * p.H + gh) * p.W + gw;
+    }
+    hm[k] = m;
+    hdst[k] = piece * 1024;
+  }
+  auto issue_halo = [&](int hc) {
+    const int c0 = hc * 16;
+    const bool first = c0 < p.C1;
+    const bf16* src = first ? x1 : x2;
+    const int vs = first ? p.vs1 : p.C2;
+    const int cc = first ? c0 : c0 - p.C1;
+    src += first ? (size_t)(cc >> 4) * p.bs1 : (size_t)cc;
+    unsigned char* dst = smem + (hc & 1) * HBUF;
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+      const bf16* g = (hm[k] >= 0 && !(p.debug & 8)) ? src + (size_t)hm[k] * vs + ((hpart >> k) & 1) * 8 : reinterpret_cast<const bf16*>(g_zero16);
+      dma16(g, dst + hdst[k]);
+    }
+  };
+  // weight fragment of (half chunk hc, tap) for this wave's n tile: 1 KiB contiguous in the fragment-order panel
+  unsigned char* ring = smem + RING0 + wave * PF * 1024;
+  auto issue_b = [&](int hc, int tap, int slot) {
+    const bf16* g = wf + ((size_t)((((hc >> 1) * 27 + tap) * 2 + (hc & 1)) * p.ntn + nt)) * 512 + lane * 8;
+    dma16((p.debug & 4) ? reinterpret_cast<const void*>(g_zero16) : reinterpret_cast<const void*>(g), ring + slot * 1024);
+  };
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  int vrow, vcol;
+  halo_row_to_hw(r, vrow, vcol);
+  int aoff[8];   // A-fragment byte offsets of the eight M tiles (d slice i >> 1, rows 4 (i & 1) ..) for the current (td, th)
+
+  // prologue: first halo half chunk, then the first PF - 1 weight fragments
+  issue_halo(hc_b);
+#pragma unroll
+  for (int q = 0; q < PF - 1; ++q) {
+    const int tq = q % 27, hq = hc_b + q / 27;
+    issue_b(hq < HC ? hq : HC - 1, tq, q % PF);
+  }
+  for (int hc = hc_b; hc < HC; ++hc) {
+    // halo(hc): issued a whole half chunk ago (or in the prologue), older than the PF - 1 weight fragments in flight
+    wait_vm_then_barrier<PF - 1>();
+    // the buffer halo(hc + 1) goes to was read during hc - 1: every wave is past those reads (barrier).  Past the end: refetch
+    // the current chunk's image into the idle buffer (keeps the counts static, nobody reads it)
+    issue_halo(hc + 1 < HC ? hc + 1 : hc);
+    const unsigned char* hb = smem + (hc & 1) * HBUF;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int td = tap / 9, th = (tap / 3) % 3, tw = tap % 3;
+      // in flight behind the fragment of this tap: PF - 2 younger fragments, and - until the fragments issued before this half
+      // chunk's gather are used up - the HPW gather pieces
+      if (tap < PF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF - 2 + HPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF - 2) : "memory");
+      const bf16x8 fb = *reinterpret_cast<const bf16x8*>(ring + (tap % PF) * 1024 + lane * 16);
+      // the eight fragment offsets of a (td, th) row of taps are computed where they are used (opaque lane terms: hipcc otherwise
+      // hoists all 72 of a half chunk out of the loop and spills them)
+      if (tw == 0) {
+        int vr = vrow, vc = vcol, hh_ = h;
+        asm volatile("" : "+v"(vr), "+v"(vc), "+v"(hh_));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int R = (i >> 1) * HALO_H + 4 * (i & 1) + vr + td * HALO_H + th;
+          aoff[i] = ((R * HALO_W + vc) * 2 + (hh_ ^ ((R >> 1) & 1))) * 16;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bf16x8 fa = *reinterpret_cast<const bf16x8*>(hb + aoff[i] + tw * 32);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
+      }
+      // refill the slot that the fragment PF - 1 taps ahead will use: the one read one tap ago (its ds_read has returned: the
+      // MFMAs of that tap consumed it)
+      {
+        const int q = tap + PF - 1;
+        const int tq = q % 27, hq = hc + q / 27;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_b(hq < HC ? hq : HC - 1, tq, q % PF);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (one tap's fragments live at a time: 36 registers, not 100)
+    }
+  }
+  wait_vm_then_barrier<0>();  // tail refetches have landed; LDS is free for the epilogue
+
+  const int n0 = nt * 32;
+  if (p.in_acc && !p.part) {
+    // InstanceNorm statistics from the fp32 accumulators: lane (r, h) holds rows of column n0 + r; one fp64 atomic pair per
+    // channel and brick, no LDS (the wave owns its 32 channels for the whole brick)
+    const bool full = d0 + HB_D <= p.D && h0 + HB_H <= p.H && w0 + HB_W <= p.W;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = acc[i][e];
+        if (!full) {
+          int hh, ww;
+          halo_row_to_hw((e & 3) + 8 * (e >> 2) + 4 * h, hh, ww);
+          if (d0 + (i >> 1) >= p.D || h0 + 4 * (i & 1) + hh >= p.H || w0 + ww >= p.W) v = 0.f;
+        }
+        s1 += v;
+        s2 += v * v;
+      }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (h == 0 && n0 + r < p.N) {
+      atomicAdd(&p.in_acc[((size_t)b * p.N + n0 + r) * 2], (double)s1);
+      atomicAdd(&p.in_acc[((size_t)b * p.N + n0 + r) * 2 + 1], (double)s2);
+    }
+  }
+
+  float* stage = reinterpret_cast<float*>(smem) + wave * 32 * STAGE_LD;
+  bf16* out = reinterpret_cast<bf16*>(p.out);
+  bf16* out2 = reinterpret_cast<bf16*>(p.out2);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int gd = d0 + (i >> 1);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) stage[((e & 3) + 8 * (e >> 2) + 4 * h) * STAGE_LD + r] = acc[i][e];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int vv = lane + 64 * q;  // 128 vectors: 32 rows x 4 groups of 8 channels
+      const int row = vv >> 2, cv = vv & 3;
+      int hh, ww;
+      halo_row_to_hw(row, hh, ww);
+      const int gh = h0 + 4 * (i & 1) + hh, gw = w0 + ww;
+      const int n = n0 + cv * 8;
+      if (gd < p.D && gh < p.H && gw < p.W && n < p.N) {
+        float xv[8];
+        load8(&stage[row * STAGE_LD + cv * 8], xv);
+        const size_t m = (((size_t)b * p.D + gd) * p.H + gh) * p.W + gw;
+        if (p.part) store8(p.part + ((size_t)blockIdx.z * p.B * p.D * p.H * p.W + m) * (p.ntn * 32) + n, xv);
+        else if (p.n_split > 0 && n >= p.n_split) {
+          if (p.residual2) {
+            float rr[8];
+            load8(reinterpret_cast<const bf16*>(p.residual2) + m * p.ldc2 + (n - p.n_split), rr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[e] += rr[e];
+          }
+          store8(out2 + m * p.ldc2 + (n - p.n_split), xv);
+        } else {
+          if (p.residual) {
+            float rr[8];
+            load8(reinterpret_cast<const bf16*>(p.residual) + m * p.ldc + n, rr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[e] += rr[e];
+          }
+          if (!(p.debug & 1)) store8(out + m * p.ldc + n, xv);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // Second pass of a channel-split convolution: out[m][n] = bf16(sum_s part[s][m][n]) and, optionally, the InstanceNorm
 // sums of the result.  grid (row chunks, B); block = (N / 8 column groups) x (256 / (N / 8) row lanes).
 __global__ __launch_bounds__(256) void halo_split_finish_kernel(const float* __restrict__ part, bf16* __restrict__ out,
@@ -665,7 +880,8 @@ template <> struct HaloDma<bf16> {
     // CTU_ROUTE_HALO_THIN: a few KiB of unused dynamic LDS push the third (NT <= 2) / second (NT = 4) resident workgroup
     // off the CU - its registers, wave slots and LDS are then free for kernels of other streams
     const size_t thin = (ctu_option_route() & CTU_ROUTE_HALO_THIN) ? (NT == 4 ? 12 * 1024 : 4 * 1024) : 0;
-    if (bp) hipLaunchKernelGGL((conv3_halo_dma_kernel<4, 2, 3, false, 4, true>), grid, dim3(256), 0, s, q);   // (two-stage ring: 70 KiB, two workgroups per CU)
+    if (NT == 4 && !bp && (ctu_option_route() & CTU_ROUTE_HALO_NSPLIT)) hipLaunchKernelGGL(conv3_halo_ns_kernel<9>, grid, dim3(256), 0, s, q);
+    else if (bp) hipLaunchKernelGGL((conv3_halo_dma_kernel<4, 2, 3, false, 4, true>), grid, dim3(256), 0, s, q);   // (two-stage ring: 70 KiB, two workgroups per CU)
     else if (NT == 4 && alone) hipLaunchKernelGGL((conv3_halo_dma_kernel<4, 3, 3, false, 0>), grid, dim3(256), thin, s, q);
     else if (NT == 4) hipLaunchKernelGGL(conv3_halo_dma_kernel<4>, grid, dim3(256), thin, s, q);
     else if (NT == 2 && long_stages) hipLaunchKernelGGL((conv3_halo_dma_kernel<2, 2, 9, false, 0>), grid, dim3(256), thin, s, q);

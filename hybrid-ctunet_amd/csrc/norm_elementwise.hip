@@ -328,6 +328,176 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Reduce AND apply in one launch, for tensors that are launch-bound rather than byte-bound (<= 32 MB: 104 of the model's 124
+// norms; their two launches cost 16 - 30 us each in the step however few bytes they move).  The grid is small enough to be
+// resident as a whole (<= 256 workgroups of <= 128 registers: four fit a CU, so up to four such launches on different streams
+// can wait at the same time without starving each other of the slots their last workgroups need).  A workgroup sums its rows,
+// adds them into sums[b] (fp64 atomics, as the reduce kernel), arrives at a counter of its batch item, waits until the
+// item's other workgroups have arrived, reads the sums back past the non-coherent L2 (agent-scope loads) and applies to the
+// SAME rows - they are still in its L1 / its XCD's L2.  sync[2 b] counts arrivals, sync[2 b + 1] departures; the last
+// workgroup to depart zeroes both, so one workspace serves every launch of a stream.  A wait that lasts 50 ms gives up
+// (counted in g_sync_timeouts: a wrong result the tests see, never a hung GPU).
+// ---------------------------------------------------------------------------------------------------------
+__device__ unsigned g_sync_timeouts;
+
+template <typename T>
+__global__ __launch_bounds__(256, 4) void in_bwd_fused_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const T* __restrict__ y, const float* __restrict__ stats,
+                                                           double* __restrict__ sums, T* __restrict__ dx, T* __restrict__ dres,
+                                                           const int64_t S, const int C, const int act,
+                                                           const int64_t rows_per_block, const uint8_t* __restrict__ mask,
+                                                           const int fold, double* __restrict__ clear, const int clear_n,
+                                                           const int64_t dxb16, unsigned* __restrict__ sync) {
+  extern __shared__ double red[];
+  const int ncg = C >> 3;
+  const int tid = threadIdx.x;
+  const int cg = tid % ncg, rl = tid / ncg;
+  const int rlanes = 256 / ncg;
+  const int b = blockIdx.y;
+  const int64_t s_begin = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t s_end = min(S, s_begin + rows_per_block);
+  if (clear && b == 0)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < clear_n; i += (int64_t)gridDim.x * 256) clear[i] = 0.0;
+  const bool active = rl < rlanes;
+  float mean[8], rstd[8];
+  if (active) in_mean_rstd(stats, b, C, cg * 8, 0.f, mean, rstd);
+  const size_t base = ((size_t)b * S) * C + cg * 8;
+  // g = dy * act'(.), xhat of one (row, column group)
+  auto fetch = [&](int64_t s, float (&g)[8], float (&xh)[8]) {
+    const size_t off = base + (size_t)s * C;
+    float xv[8];
+    load8(dy + off, g);
+    load8(x + off, xv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xh[e] = (xv[e] - mean[e]) * rstd[e];
+    if (act) {
+      if (mask) {
+        const unsigned bits = mask[((size_t)b * S + s) * ncg + cg];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = ((bits >> e) & 1u) ? g[e] : g[e] * LRELU_SLOPE;
+      } else if (y) {
+        float yv[8];
+        load8(y + off, yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = yv[e] > 0.f ? g[e] : g[e] * LRELU_SLOPE;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = xh[e] > 0.f ? g[e] : g[e] * LRELU_SLOPE;
+      }
+    }
+  };
+  double s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.0; s2[e] = 0.0; }
+  if (active) {
+    for (int64_t s = s_begin + rl; s < s_end; s += 2 * rlanes) {   // two rows in flight per thread
+      float g0[8], h0[8], g1[8], h1[8];
+      const bool two = s + rlanes < s_end;
+      fetch(s, g0, h0);
+      if (two) fetch(s + rlanes, g1, h1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s1[e] += (double)g0[e];
+        s2[e] += (double)g0[e] * (double)h0[e];
+      }
+      if (two) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s1[e] += (double)g1[e];
+          s2[e] += (double)g1[e] * (double)h1[e];
+        }
+      }
+    }
+  }
+  if (fold) {
+    for (int d = ncg; d < 64; d <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s1[e] += __shfl_xor(s1[e], d, 64);
+        s2[e] += __shfl_xor(s2[e], d, 64);
+      }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane < ncg) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { red[(wave * ncg + lane) * 16 + e] = s1[e]; red[(wave * ncg + lane) * 16 + 8 + e] = s2[e]; }
+    }
+    __syncthreads();
+    for (int o = tid; o < C * 2; o += 256) {
+      const int c = o >> 1, which = o & 1;
+      const int g = c >> 3, e = c & 7;
+      double acc = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) acc += red[(w * ncg + g) * 16 + which * 8 + e];
+      const double old = atomicAdd(&sums[((size_t)b * C + c) * 2 + which], acc);   // returning form: back = performed at the memory side
+      asm volatile("" ::"v"(old));
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s1[e]; red[tid * 16 + 8 + e] = s2[e]; }
+    __syncthreads();
+    for (int o = tid; o < C * 2; o += 256) {
+      const int c = o >> 1, which = o & 1;
+      const int g = c >> 3, e = c & 7;
+      double acc = 0.0;
+      for (int r = 0; r < rlanes; ++r) acc += red[(r * ncg + g) * 16 + which * 8 + e];
+      const double old = atomicAdd(&sums[((size_t)b * C + c) * 2 + which], acc);
+      asm volatile("" ::"v"(old));
+    }
+  }
+  // ---- the item's workgroups meet.  No fences (an agent-scope release writes the XCD's whole L2 back, an acquire invalidates it:
+  // 25 us per launch, measured): the sums are only ever touched by memory-side atomics and agent-scope (L2-bypassing) loads, the
+  // returning adds above are back - i.e. performed - before the barrier, and the counter is a memory-side atomic polled past L2
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned n = gridDim.x;
+    __hip_atomic_fetch_add(&sync[2 * b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(&sync[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
+      __builtin_amdgcn_s_sleep(2);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) {   // 50 ms at 100 MHz
+        atomicAdd(&g_sync_timeouts, 1u);
+        break;
+      }
+    }
+    const unsigned gone = __hip_atomic_fetch_add(&sync[2 * b + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gone == n - 1) {   // everybody is past the wait: hand the counters back zeroed
+      __hip_atomic_store(&sync[2 * b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sync[2 * b + 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  // ---- apply to the same rows
+  float m1[8], m2[8];
+  const double inv_s = 1.0 / (double)S;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const double* sp = &sums[((size_t)b * C + cg * 8 + e) * 2];
+    m1[e] = (float)(__hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * inv_s);
+    m2[e] = (float)(__hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * inv_s);
+  }
+  T* dxblk = dx + ((size_t)(cg >> 1) * dxb16 + (size_t)b * S) * 16 + (cg & 1) * 8;  // CTU_LAYOUT_B16 destination (dxb16 > 0)
+  auto put = [&](int64_t s, const float (&g)[8], const float (&xh)[8]) {
+    const size_t off = base + (size_t)s * C;
+    if (dres) store8(dres + off, g);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = rstd[e] * (g[e] - m1[e] - xh[e] * m2[e]);
+    if (dxb16) store8(dxblk + (size_t)s * 16, o);
+    else store8(dx + off, o);
+  };
+  for (int64_t s = s_begin + rl; s < s_end; s += 2 * rlanes) {
+    float g0[8], h0[8], g1[8], h1[8];
+    const bool two = s + rlanes < s_end;
+    fetch(s, g0, h0);
+    if (two) fetch(s + rlanes, g1, h1);
+    put(s, g0, h0);
+    if (two) put(s + rlanes, g1, h1);
+  }
+}
+
 // grid.x for the streaming kernels: ~8192 workgroups in total, a multiple of C/8 so a thread's column group is fixed
 static unsigned in_stream_grid(int64_t S, int C, int B) {
   const int ncg = C / 8;
@@ -458,6 +628,44 @@ extern "C" int ctu_in_bwd_apply(ctu_dtype dtype, const void* dy, const void* x, 
                hipLaunchKernelGGL(in_bwd_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, (const bf16*)x,
                                   (const bf16*)y, stats, sums, (bf16*)dx, (bf16*)dres, S, C, act, clear_ws, clear_n, dxb16, sign_mask));
   return ctu_check_launch("in_bwd_apply");
+}
+
+extern "C" int ctu_in_bwd_fused(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,
+                                double* sums, void* dx, void* dres, int32_t B, int64_t S, int32_t C, int32_t act,
+                                double* clear_ws, int32_t clear_n, int32_t dx_layout, const uint8_t* sign_mask,
+                                uint32_t* sync_ws, ctu_stream_t stream) {
+  if (int rc = check_in(x, B, S, C)) return rc;
+  CTU_REQUIRE(dy && stats && sums && dx && sync_ws, "in_bwd_fused: null pointer");
+  CTU_REQUIRE(B <= CTU_IN_FUSED_MAX_WG, "in_bwd_fused: at most %d batch items (one workgroup each at least)", CTU_IN_FUSED_MAX_WG);
+  CTU_REQUIRE(dx_layout == CTU_LAYOUT_NDHWC || (dx_layout == CTU_LAYOUT_B16 && C % 16 == 0 && dx != dy && dx != x),
+              "in_bwd_fused: bad output layout");
+  const int64_t dxb16 = dx_layout == CTU_LAYOUT_B16 ? (int64_t)B * S : 0;
+  CTU_REQUIRE(clear_n >= 0 && (clear_n == 0 || clear_ws) && clear_ws != sums, "in_bwd_fused: bad clear workspace");
+  // the whole grid has to be resident at once: <= CTU_IN_FUSED_MAX_WG workgroups, at least 16 rows each
+  int64_t chunks = CTU_IN_FUSED_MAX_WG / B;
+  int64_t rows = (S + chunks - 1) / chunks;
+  if (rows < 16) rows = 16;
+  chunks = (S + rows - 1) / rows;
+  dim3 grid((unsigned)chunks, B);
+  hipStream_t s = (hipStream_t)stream;
+  const int ncg = C / 8;
+  const int fold = ncg <= 64 && (ncg & (ncg - 1)) == 0;
+  const size_t lds = fold ? (size_t)4 * ncg * 16 * sizeof(double) : (size_t)256 * 16 * sizeof(double);
+  CTU_DISPATCH(dtype,
+               hipLaunchKernelGGL(in_bwd_fused_kernel<float>, grid, dim3(256), lds, s, (const float*)dy, (const float*)x,
+                                  (const float*)y, stats, sums, (float*)dx, (float*)dres, S, C, act, rows, sign_mask, fold, clear_ws,
+                                  clear_n, dxb16, sync_ws),
+               hipLaunchKernelGGL(in_bwd_fused_kernel<bf16>, grid, dim3(256), lds, s, (const bf16*)dy, (const bf16*)x,
+                                  (const bf16*)y, stats, sums, (bf16*)dx, (bf16*)dres, S, C, act, rows, sign_mask, fold, clear_ws,
+                                  clear_n, dxb16, sync_ws));
+  return ctu_check_launch("in_bwd_fused");
+}
+
+// number of in-kernel waits that gave up since the library was loaded (synchronises the device; tests and bench.py read it)
+extern "C" int ctu_sync_timeouts(void) {
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_sync_timeouts), sizeof(v)) != hipSuccess) return -1;
+  return (int)v;
 }
 
 // =========================================================================================================

@@ -474,7 +474,11 @@ class _VitBranch(_Base):
 
     def _vit_pyramid(self, x):
         """ViT trunk + window-attention pyramid (hybrid_CTUNet.py:821,824): [768@6.6.12, 512@12.12.24, ..., 64@96^3]."""
-        return self.vit_encoder(self.proj_feat(self.vit(x[..., 0])))
+        feats = self.vit_encoder(ops.trace_point(self.proj_feat(self.vit(x[..., 0])), "vit trunk"))
+        if ops.TRACE is not None:
+            feats = list(feats)
+            feats[-1] = ops.trace_point(feats[-1], "window stages")
+        return feats
 
     def _vit_heads(self, x, vit_enc, enc0=None):
         """vit_encoder0 / vit_decoder0 and the two ViT-branch heads (hybrid_CTUNet.py:822,831-835).  enc0: vit_encoder0(x) when
@@ -565,7 +569,7 @@ class CTUNet(_VitBranch):
                 for d, e, v in ((self.res_decoder3, res_enc3, vit_enc[1]), (self.res_decoder2, res_enc2, vit_enc[2]),
                                 (self.res_decoder1, res_enc1, vit_enc[3])):
                     e.record_stream(side)
-                    t = d.skip_path(e, v)
+                    t = ops.trace_point(d.skip_path(e, v), f"skip{3 - len(skips)}")
                     t.record_stream(main)   # allocated in the side stream's pool, consumed on the main stream
                     ev = torch.cuda.Event()
                     ev.record(side)
@@ -574,6 +578,7 @@ class CTUNet(_VitBranch):
                 if enc0_ready is not None:
                     side.wait_event(enc0_ready)
                 vit_logits, vit_96x96 = self._vit_heads(x, vit_enc, enc0)   # needed by the loss only
+                vit_logits = ops.trace_point(vit_logits, "vit heads")
                 for t in (vit_logits, vit_96x96):
                     t.record_stream(main)
             x.record_stream(side)
@@ -582,7 +587,7 @@ class CTUNet(_VitBranch):
             for d, t, ev, st in zip((self.res_decoder3, self.res_decoder2, self.res_decoder1), skips, skip_ready,
                                     (None, None, stash2)):   # res_decoder1's transposed conv reads res_dec2
                 main.wait_event(ev)
-                res_dec = d.main_path(res_dec, t, grad_stash=st)
+                res_dec = ops.trace_point(d.main_path(res_dec, t, grad_stash=st), f"dec{3 - len(decs)}")
                 decs.append(res_dec)
             res_dec3, res_dec2, res_dec1 = decs
             join_side = True
@@ -593,10 +598,10 @@ class CTUNet(_VitBranch):
             res_dec2 = self.res_decoder2(res_dec3, res_enc2, vit_enc[2])
             res_dec1 = self.res_decoder1.main_path(res_dec2, self.res_decoder1.skip_path(res_enc1, vit_enc[3]), grad_stash=stash2)
         park = lambda t, st: ops.GradStash.apply(t, st) if (st is not None and t.requires_grad) else t
-        res_out = self.res_decoder0(res_dec1, grad_stash=stash1 if res_dec1.requires_grad else None)
+        res_out = ops.trace_point(self.res_decoder0(res_dec1, grad_stash=stash1 if res_dec1.requires_grad else None), "dec0")
         res_logits = self.res_out(res_out)
         res_logits_48x48 = self.res_out_48x48(park(res_dec1, stash1))
-        res_logits_24x24 = self.res_out_24x24(park(res_dec2, stash2))
+        res_logits_24x24 = ops.trace_point(self.res_out_24x24(park(res_dec2, stash2)), "res heads")
         if join_side:
             torch.cuda.current_stream().wait_stream(ops.side_stream(x.device))   # the ViT-branch logits
         return self._outputs(((res_logits, res_logits_48x48, res_logits_24x24), (vit_logits, vit_96x96)))

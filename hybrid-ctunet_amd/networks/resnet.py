@@ -178,10 +178,10 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = ops.instance_norm(self.conv1(x), None, True)
+        x = ops.trace_point(ops.instance_norm(self.conv1(x), None, True), "stem")
         features = []
-        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
-            x = layer(x)
+        for i, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
+            x = ops.trace_point(layer(x), f"layer{i + 1}")
             features.append(x)
         return features
 

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import math
 import os
+import time
 import weakref
 from typing import Optional, Sequence, Tuple
 
@@ -580,6 +581,38 @@ class GradStash(torch.autograd.Function):
         _stash_watch.append(ctx.slot)
         ensure_join_after_backward()
         return None, None
+
+
+# Measurement only (tools/step_trace.py): with TRACE a list, trace_point(t, label) records a HIP event on the current stream where the
+# forward pass queues it and - through an identity autograd node - where the backward pass reaches the same point, each with the host
+# time of the enqueue.  TRACE is None in production: trace_point returns its argument and nothing is recorded.
+TRACE = None
+
+
+def mark(label: str):
+    if TRACE is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        TRACE.append((label, torch.cuda.current_stream().cuda_stream, ev, time.perf_counter()))
+
+
+class _TraceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, label):
+        ctx.label = label
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        mark("bwd:" + ctx.label)
+        return g, None
+
+
+def trace_point(t, label: str):
+    if TRACE is None:
+        return t
+    mark(label)
+    return _TraceFn.apply(t, label) if (torch.is_grad_enabled() and t.requires_grad) else t
 
 
 def linear(x, weight, bias=None, residual=None, act: int = 0, in_stats: bool = False, grad_stash=None):

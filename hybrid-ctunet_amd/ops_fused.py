@@ -34,8 +34,12 @@ OPT = {"gelu2": 1,    # GELU backward inside the data-gradient GEMM of the Linea
        "wparam": 1,   # halo weight gradients reduced straight into the parameter layout (ctu_conv3_halo_wgrad_param)
        "s2": 1,       # stride-2 data gradients of the stage transitions: 3x3x3 on the halo kernel over the zero-upsampled dY,
                       # 1x1x1 as a plain GEMM over the output rows + ctu_add_strided2 (instead of the generic implicit GEMM)
-       "nogres": 1}   # blocks with a conv + norm shortcut: that norm's backward reads the block's gradient and sign mask itself
+       "nogres": 1,   # blocks with a conv + norm shortcut: that norm's backward reads the block's gradient and sign mask itself
                       # instead of a copy with the LeakyReLU slope applied, written by the main norm's backward (one tensor pass)
+       "in1": 0}      # InstanceNorm backward of tensors up to IN_FUSED_BYTES as ONE launch (ctu_in_bwd_fused: reduce, meet at a counter, apply).
+                      # Built, parity-tested and measured SLOWER: 21 - 57 us against 13 - 43 for the pair in kbench, 47.4 - 47.8 against
+                      # 45.8 - 45.9 ms per step (profiles/r04_experiment_in_bwd_one_launch.log) - two launches of one stream pipeline, a
+                      # grid-wide meet (returning atomics, counter poll, sums read past L2) is a 10 us chain.  Off.
 for _kv in filter(None, os.environ.get("CTU_OPT", "").split(",")):
     _k, _, _v = _kv.partition("=")
     if _k not in OPT:
@@ -64,7 +68,7 @@ def _flags():
 # per-(device, stream) state of the fused path
 # ---------------------------------------------------------------------------------------------------------------
 class _WS:
-    __slots__ = ("acc", "apar", "adirty", "sums", "par", "dirty_n")
+    __slots__ = ("acc", "apar", "adirty", "sums", "par", "dirty_n", "insync")
 
     def __init__(self, device):
         # InstanceNorm forward statistics: two fp64 accumulators alternate from norm to norm - a producer's epilogue sums into
@@ -75,12 +79,14 @@ class _WS:
         self.sums = [torch.zeros(1 << 14, dtype=torch.float64, device=device) for _ in range(2)]  # IN backward sums, same scheme
         self.par = 0
         self.dirty_n = 0
+        self.insync = torch.zeros(128, dtype=torch.int32, device=device)   # arrival / departure counters of ctu_in_bwd_fused
 
 
 _FWS: Dict[tuple, _WS] = {}
 # (mean, rstd) tables of a plan sit 32 KiB apart and the fp64 accumulators hold 1 << 14 entries: a block whose widest norm has
 # more than 8192 / 2 (batch item, channel) pairs takes the per-op path, whose workspaces grow on demand (bottleneck_ok, resblock_ok)
 STATS_MAX = 8192
+IN_FUSED_BYTES = 32 << 20   # norms whose tensor is larger keep the reduce + apply pair (byte-bound: 8 192 workgroups stream better than 256)
 
 
 def _fws(device, sid) -> _WS:
@@ -207,8 +213,12 @@ class _InBwd:
         R = self.R
         sums, clear = (R["s0"], R["s1"]) if self.k % 2 == 0 else (R["s1"], R["s0"])
         clear_n = R.ival("dirty0") if self.k == 0 else self.prev
-        R.call("ctu_in_bwd_reduce", BF16, gy, x, y, stats, sums, B, S, C, int(act), mask)
-        R.call("ctu_in_bwd_apply", BF16, gy, x, y, stats, sums, gx, gres, B, S, C, int(act), clear, clear_n, int(dx_b16), mask)
+        if OPT["in1"] and B * S * C * 2 <= IN_FUSED_BYTES and B <= 64:
+            R.call("ctu_in_bwd_fused", BF16, gy, x, y, stats, sums, gx, gres, B, S, C, int(act), clear, clear_n, int(dx_b16), mask,
+                   R["insync"])
+        else:
+            R.call("ctu_in_bwd_reduce", BF16, gy, x, y, stats, sums, B, S, C, int(act), mask)
+            R.call("ctu_in_bwd_apply", BF16, gy, x, y, stats, sums, gx, gres, B, S, C, int(act), clear, clear_n, int(dx_b16), mask)
         self.k += 1
         self.prev = B * C * 2
         if self.prev > STATS_MAX:
@@ -378,7 +388,7 @@ def em_conv_wgrad(R, need, spec: ConvSpec, gy, x1, x2, gw, *, stream, x1_b16=0, 
 # shared run-time plumbing
 # ---------------------------------------------------------------------------------------------------------------
 WS_NAMES = ("ia0", "ia1", "iadirty", "tnws", "skws")
-BWD_WS_NAMES = ("s0", "s1", "dirty0", "tnws", "skws", "tnws1", "panel", "wgws")
+BWD_WS_NAMES = ("s0", "s1", "dirty0", "tnws", "skws", "tnws1", "panel", "wgws", "insync")
 
 
 def _fwd_ws_values(device, sid, need: _Need, n_norms: int, last_n: int):
@@ -430,7 +440,7 @@ class _BwdRun:
         vals = [w.sums[w.par].data_ptr(), w.sums[1 - w.par].data_ptr(), w.dirty_n,
                 ops._tn_workspace(dev).data_ptr(), ops._splitk_workspace(dev, need.skws).data_ptr(),
                 _tn_ws_for(key1).data_ptr(), _panel_for(key1, need.panel).data_ptr(),
-                _wgws_for(key1).data_ptr() if ops.WGRAD_PARTIALS else 0]
+                _wgws_for(key1).data_ptr() if ops.WGRAD_PARTIALS else 0, w.insync.data_ptr()]
         return vals, w
 
     def keep_alive(self, *tensors):

@@ -249,6 +249,18 @@ int ctu_in_bwd_apply(ctu_dtype dtype, const void* dy, const void* x, const void*
                      const double* sums, void* dx, void* dres, int32_t B, int64_t S, int32_t C, int32_t act,
                      double* clear_ws, int32_t clear_n, int32_t dx_layout, const uint8_t* sign_mask, ctu_stream_t stream);
 
+/* ctu_in_bwd_reduce + ctu_in_bwd_apply in ONE launch, for tensors whose two launches cost more than their bytes (the callers
+ * use it up to 32 MB; resnet.py:106-126 and hybrid_CTUNet.py:93-105 backward).  Same arguments, same arithmetic and the same
+ * alternating-sums protocol; the grid is at most CTU_IN_FUSED_MAX_WG workgroups, all resident, which meet per batch item at a
+ * counter between the two phases.  sync_ws: 2 * B uint32 words, zero before the first launch and handed back zeroed (one
+ * per stream).  A wait longer than 50 ms gives up and is counted (ctu_sync_timeouts). */
+#define CTU_IN_FUSED_MAX_WG 256
+int ctu_in_bwd_fused(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats, double* sums,
+                     void* dx, void* dres, int32_t B, int64_t S, int32_t C, int32_t act, double* clear_ws, int32_t clear_n,
+                     int32_t dx_layout, const uint8_t* sign_mask, uint32_t* sync_ws, ctu_stream_t stream);
+/* in-kernel waits that gave up since the library was loaded (0 in a healthy run); synchronises the device */
+int ctu_sync_timeouts(void);
+
 /* K8 LayerNorm (eps 1e-5, affine) (vit.py:35,55,116,118; hybrid_CTUNet.py:456,518,630-631).
  * x,y: [rows][dim]; mean_rstd: fp32 [rows][2]; dgamma/dbeta: fp32 [dim], accumulated (atomics). */
 int ctu_layernorm_fwd(ctu_dtype dtype, const void* x, const float* gamma, const float* beta, void* y,

@@ -206,3 +206,96 @@ def test_cross_weight_block_fused_equals_per_op(dim, vol, direct):
     assert F.pwa_block_ok(m, *xs[0])
     _compare(m, xs, direct)
     assert any(k[0] == "pwa" for k in F._cache)
+
+
+def test_vit_trunk_with_inner_width_other_than_dim_takes_the_per_op_path():
+    """num_heads is a reference CLI flag (main_CTUNet.py:59): 256 wide with 2 heads of 64 has an inner width of 128.  The fused
+    trunk sizes its buffers from `dim`, so it must decline, and the shape-generic per-op path must give gradients of the
+    parameters' own shapes."""
+    from hybrid_ctunet_amd.networks import vit as V
+    from hybrid_ctunet_amd import ops_fused as F
+    torch.manual_seed(0)
+
+    class Trunk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.transformer = torch.nn.ModuleList([V.TransformerBlock(256, 2, 64, 512) for _ in range(2)])
+            self.dropout = torch.nn.Dropout(0.0)
+            self.took_fused = None
+
+        def forward(self, x):
+            self.took_fused = F.vit_trunk_ok(self, x)
+            if self.took_fused:
+                return F.vit_trunk(self.transformer, x)
+            for b in self.transformer:
+                x = b(x)
+            return x
+
+    m = Trunk().cuda()
+    assert tuple(m.transformer[0].attn.to_qkv.weight.shape) == (3 * 128, 256)
+    x = torch.randn(2, 432, 256, device="cuda").to(torch.bfloat16)
+    assert not F.vit_trunk_ok(m, x)
+    n_before = sum(k[0] == "vit" for k in F._cache)
+    xs = [x, torch.randn(2, 432, 256, device="cuda").to(torch.bfloat16)]
+    _compare(m, xs, True)          # both runs on the per-op path: identical kernels, and no write outside a parameter's gradient
+    assert m.took_fused is False and sum(k[0] == "vit" for k in F._cache) == n_before
+    # against float64 math on the CPU: attention with inner width 128 under a 256-wide residual stream
+    ref = Trunk().double()
+    ref.load_state_dict({k: v.double().cpu() for k, v in m.state_dict().items()})
+    xr = x.double().cpu().requires_grad_(True)
+    h = xr
+    for b in ref.transformer:
+        a = b.attn
+        t = torch.nn.functional.layer_norm(h, (256,), a.norm.weight, a.norm.bias, 1e-5)
+        q, k, v = (t @ a.to_qkv.weight.t()).chunk(3, dim=-1)
+        sp = lambda z: z.view(2, 432, 2, 64).transpose(1, 2)  # noqa: E731
+        o = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * a.scale, dim=-1) @ sp(v)
+        h = h + o.transpose(1, 2).reshape(2, 432, 128) @ a.to_out[0].weight.t() + a.to_out[0].bias
+        f = b.ff.net
+        t = torch.nn.functional.layer_norm(h, (256,), f[0].weight, f[0].bias, 1e-5)
+        h = h + torch.nn.functional.gelu(t @ f[1].weight.t() + f[1].bias) @ f[4].weight.t() + f[4].bias
+    out = m(x.clone())
+    err = ((out.double().cpu() - h.detach()).abs().max() / h.detach().abs().max()).item()
+    assert err <= 3e-2, err
+
+
+def test_bottleneck_beyond_the_fixed_statistics_tables_takes_the_per_op_path():
+    """layer4-shaped block (N4 = 1024) at a per-GPU batch of 5: B * N4 * 2 exceeds the fused plan's 8192-entry tables, so
+    bottleneck_ok declines and the per-op path (workspaces grown on demand) runs."""
+    from hybrid_ctunet_amd.networks import resnet as R
+    from hybrid_ctunet_amd import ops_fused as F
+    torch.manual_seed(0)
+    blk = R.Bottleneck(1024, 256, stride=(1, 1, 1), downsample=None).cuda()
+    x = torch.randn(5, 3, 3, 6, 1024, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    assert not F.bottleneck_ok(blk, x)
+    assert F.bottleneck_ok(blk, x[:4])
+    n_before = sum(k[0] == "bneck" for k in F._cache)
+    y = blk(x)
+    y.backward(torch.randn_like(y))
+    torch.cuda.synchronize()
+    assert sum(k[0] == "bneck" for k in F._cache) == n_before
+    assert torch.isfinite(y.float()).all() and torch.isfinite(x.grad.float()).all()
+    # the same items through the fused path in two admissible batches: same numbers (InstanceNorm is per item)
+    xa = x.detach()[:4].clone().requires_grad_(True)
+    ya = blk(xa)
+    assert (ya.float() - y[:4].float()).abs().max().item() <= 2e-2 * y.float().abs().max().item()
+
+
+def test_halo_wgrad_param_clamps_its_splits_to_the_workspace():
+    """192 weight tiles (N = 512, K = 768) make 2 splits = 21.2 M floats of partial panels against the 15.9 M-float workspace
+    every caller passes: the entry point now walks longer brick ranges instead of failing."""
+    from hybrid_ctunet_amd._lib import call, dcode, ptr, stream
+    torch.manual_seed(0)
+    B, D, H, W, C, N = 1, 4, 8, 16, 768, 512
+    x = (torch.randn(B, D, H, W, C, device="cuda") * 0.5).to(torch.bfloat16)
+    dy = (torch.randn(B, D, H, W, N, device="cuda") * 0.5).to(torch.bfloat16)
+    ws = torch.empty(256 * 54 * 1024 + 27 * 64 * 1024, device="cuda")
+    gw = torch.zeros(N, C, 3, 3, 3, device="cuda")
+    call("ctu_conv3_halo_wgrad_param", dcode(x.dtype), ptr(dy), ptr(x), None, ptr(gw), B, D, H, W, C, 0, N, 0, 0, ptr(ws), ws.numel(),
+         stream())
+    torch.cuda.synchronize()
+    xr = x.float().permute(0, 4, 1, 2, 3).requires_grad_(False)
+    wr = torch.zeros(N, C, 3, 3, 3, device="cuda", requires_grad=True)
+    torch.nn.functional.conv3d(xr, wr, padding=1).backward(dy.float().permute(0, 4, 1, 2, 3))
+    err = ((gw - wr.grad).abs().max() / wr.grad.abs().max()).item()
+    assert err <= 2e-3, err

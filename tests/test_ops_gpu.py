@@ -857,3 +857,125 @@ def test_grad_stash_without_its_consumer_raises(ops):
     torch.cuda.synchronize()
     ref = (torch.ones(64, 32, device="cuda") @ w.detach()) + 2.0
     assert torch.allclose(x.grad, ref, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,S,C,act,use_mask,use_y,want_res,b16", [
+    (2, 3456, 128, 1, False, False, False, 0),     # layer3 gn1 / gn2
+    (2, 3456, 512, 1, True, False, True, 0),       # layer3 gn3: sign mask + gradient of the shortcut
+    (2, 432, 1024, 1, False, True, False, 0),      # layer4 gn3 reading y; 27 rows of 16 per item
+    (2, 27648, 64, 1, False, False, False, 1),     # layer2 gn1: dx in CTU_LAYOUT_B16
+    (2, 1000, 96, 0, False, False, False, 0),      # no activation (shortcut norm), ragged rows, C / 8 not a power of two
+    (3, 777, 2048, 1, False, False, False, 0),     # widest row, three items
+    (1, 221184, 32, 1, False, False, False, 1),    # 864 rows per workgroup
+])
+def test_instance_norm_backward_in_one_launch(ops, dtype, B, S, C, act, use_mask, use_y, want_res, b16):
+    """ctu_in_bwd_fused (reduce, meet at a counter, apply: one launch) against the ctu_in_bwd_reduce + ctu_in_bwd_apply pair on the
+    same tensors - same arithmetic, only the order of the fp64 atomics is free - and against float64 math; run three times on one
+    sync workspace (the counters hand themselves back zeroed) with the two sums buffers alternating as the launch lists do."""
+    from hybrid_ctunet_amd._lib import call, dcode, lib, ptr, stream
+    if b16 and dtype != torch.bfloat16:
+        pytest.skip("CTU_LAYOUT_B16 is a bf16 layout")
+    g = torch.Generator().manual_seed(S + C)
+    x = (torch.randn(B, S, C, generator=g) * 1.5 + 0.3).to(dtype).cuda()
+    dy = torch.randn(B, S, C, generator=g).to(dtype).cuda()
+    res = torch.randn(B, S, C, generator=g).to(dtype).cuda() if (use_mask or use_y) else None
+    xd = x.double()
+    mean, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    stats = torch.stack([mean.squeeze(1), rstd.squeeze(1)], dim=-1).float().contiguous()
+    xhat = (xd - mean) * rstd
+    pre = xhat + (res.double() if res is not None else 0.0)
+    yv = torch.where(pre > 0, pre, 0.01 * pre).to(dtype) if act else pre.to(dtype)
+    mask = None
+    if use_mask:
+        bits = (pre > 0).view(B, S, C // 8, 8).to(torch.int32) << torch.arange(8, device="cuda", dtype=torch.int32)
+        mask = bits.sum(-1).to(torch.uint8).contiguous()
+    ypass = yv if use_y else None
+    gref = dy.double() * (torch.where(pre > 0, 1.0, 0.01) if act else 1.0)
+    dx_ref = rstd * (gref - gref.mean(1, keepdim=True) - xhat * (gref * xhat).mean(1, keepdim=True))
+
+    def unblock(t):   # CTU_LAYOUT_B16 [C/16][B*S][16] -> [B, S, C]
+        return t.view(C // 16, B * S, 16).permute(1, 0, 2).reshape(B, S, C) if b16 else t
+    sums = [torch.zeros(B * C * 2, dtype=torch.float64, device="cuda") for _ in range(2)]
+    sync = torch.zeros(128, dtype=torch.int32, device="cuda")
+    dx_p, dres_p = torch.empty_like(x), (torch.empty_like(x) if want_res else None)
+    call("ctu_in_bwd_reduce", dcode(dtype), ptr(dy), ptr(x), ptr(ypass), ptr(stats), ptr(sums[0]), B, S, C, act, ptr(mask), stream())
+    call("ctu_in_bwd_apply", dcode(dtype), ptr(dy), ptr(x), ptr(ypass), ptr(stats), ptr(sums[0]), ptr(dx_p), ptr(dres_p), B, S, C, act,
+         ptr(sums[1]), B * C * 2, b16, ptr(mask), stream())
+    sums_pair = sums[0].clone()
+    sums[0].zero_()
+    for rep in range(3):
+        cur, other = sums[rep & 1], sums[1 - (rep & 1)]
+        dx_f, dres_f = torch.full_like(x, float("nan")), (torch.full_like(x, float("nan")) if want_res else None)
+        call("ctu_in_bwd_fused", dcode(dtype), ptr(dy), ptr(x), ptr(ypass), ptr(stats), ptr(cur), ptr(dx_f), ptr(dres_f), B, S, C, act,
+             ptr(other), B * C * 2, b16, ptr(mask), ptr(sync), stream())
+        torch.cuda.synchronize()
+        assert int(sync.abs().sum()) == 0, "the counters come back zeroed"
+        assert int(other.abs().sum()) == 0, "the other sums buffer was cleared"
+        assert torch.allclose(cur, sums_pair, rtol=1e-9, atol=1e-9 * float(sums_pair.abs().max()) + 1e-12)
+        close(unblock(dx_f), dx_ref.cpu(), dtype, f"dx[{rep}] vs float64", scale=float(dx_ref.abs().max()))
+        d = (unblock(dx_f).float() - unblock(dx_p).float()).abs().max().item()
+        # (fp32 outputs show the last bit of the differently ordered fp64 sums; bf16 outputs round it away almost everywhere)
+        lim, same = (2e-2, 0.97) if dtype == torch.bfloat16 else (1e-5, 0.5)
+        assert d <= lim * dx_p.float().abs().max().item() and (dx_f == dx_p).float().mean().item() > same, ("vs the pair", d)
+        if want_res:
+            assert torch.equal(dres_f, dres_p)
+    assert lib().ctu_sync_timeouts() == 0
+
+
+@pytest.mark.parametrize("case", [(2, 8, 16, 16, 128, 128, 0), (1, 5, 9, 11, 128, 128, 0), (2, 4, 8, 8, 96, 256, 0), (1, 9, 17, 10, 64, 128, 64),
+                                  (1, 6, 9, 9, 32, 128, 0), (2, 6, 6, 12, 256, 256, 0)])
+def test_conv3d_halo_n_split_bit_equal(ops, case):
+    """conv3_halo_ns_kernel (ctu_set_option("route", 4096): a wave owns one n tile for the whole brick, wave-private weight rings, one
+    barrier per half chunk) against conv3_halo_dma_kernel: the same products summed in the same order per accumulator, so forward
+    output and data gradient are bit-equal; the fused InstanceNorm sums agree to fp32 rounding of the per-brick partial sums.
+    Ragged volumes, concat input (second source), one to sixteen half chunks, the channel-split small-volume path, residual inputs
+    (GradStash route of the data gradient)."""
+    from hybrid_ctunet_amd import _lib
+    from hybrid_ctunet_amd._lib import call, dcode, ptr, stream
+    B, D, H, W, C, N, C2 = case
+    x0 = rnd((B, D, H, W, C), 61).to(torch.bfloat16).cuda()
+    x2 = rnd((B, D, H, W, C2), 64).to(torch.bfloat16).cuda() if C2 else None
+    w = torch.nn.Parameter(rnd((N, C + C2, 3, 3, 3), 62, 1 / math.sqrt(27 * (C + C2))).float().cuda())
+    gout = rnd((B, D, H, W, N), 63).to(torch.bfloat16).cuda()
+
+    def run(rt):
+        _lib.call("ctu_set_option", b"route", rt)
+        try:
+            x = x0.clone().requires_grad_(True)
+            xb = x2.clone().requires_grad_(True) if x2 is not None else None
+            w.grad = None
+            y = ops.conv3d(x, w, 1, 1, x2=xb) if xb is not None else ops.conv3d(x, w, 1, 1)
+            y.backward(gout)
+            torch.cuda.synchronize()
+            return y.detach().clone(), x.grad.clone(), (xb.grad.clone() if xb is not None else None)
+        finally:
+            _lib.call("ctu_set_option", b"route", 0)
+    a, b = run(0), run(4096)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    if x2 is not None:
+        assert torch.equal(a[2], b[2])
+    # fused statistics + a residual in the epilogue, straight through the C ABI
+    wfr = ops._pack_frag(w, N, C + C2, 27, (C + C2) * 27, 27, 1, 0, torch.bfloat16)
+    res = rnd((B, D, H, W, N), 65).to(torch.bfloat16).cuda()
+    ws = torch.zeros(1 << 22, device="cuda")
+    outs, accs = [], []
+    for rt in (0, 4096):
+        _lib.call("ctu_set_option", b"route", rt)
+        try:
+            out = torch.empty(B, D, H, W, N, device="cuda", dtype=torch.bfloat16)
+            acc = torch.zeros(B * N * 2, device="cuda", dtype=torch.float64)
+            call("ctu_conv3_halo", dcode(torch.bfloat16), ptr(x0), ptr(x2), ptr(wfr), ptr(out), None, B, D, H, W, C, C2, N, 0, N, 0,
+                 ptr(acc), None, None, None, 0, 0, stream())
+            out_r = torch.empty_like(out)
+            call("ctu_conv3_halo", dcode(torch.bfloat16), ptr(x0), ptr(x2), ptr(wfr), ptr(out_r), None, B, D, H, W, C, C2, N, 0, N, 0,
+                 None, ptr(res), None, None, 0, 0, stream())
+            torch.cuda.synchronize()
+            outs.append((out, out_r))
+            accs.append(acc)
+        finally:
+            _lib.call("ctu_set_option", b"route", 0)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.allclose(accs[0], accs[1], rtol=1e-5, atol=1e-5 * float(accs[0].abs().max()))
+    del ws

@@ -109,10 +109,25 @@ def inorm(B, D, H, W, C, sets=3):
         i = nxt()
         call("ctu_in_bwd_apply", dcode(DT), ptr(gs[i]), ptr(xs[i]), None, ptr(stats), ptr(sums), ptr(ys[i]), None, B, S, C, 1,
              ptr(dirty), B * C * 2, LAYOUT, None, stream())
+    sync = torch.zeros(128, device=dev, dtype=torch.int32)
+
+    def f_pair():
+        i = nxt()
+        call("ctu_in_bwd_reduce", dcode(DT), ptr(gs[i]), ptr(xs[i]), None, ptr(stats), ptr(sums), B, S, C, 1, None, stream())
+        call("ctu_in_bwd_apply", dcode(DT), ptr(gs[i]), ptr(xs[i]), None, ptr(stats), ptr(sums), ptr(ys[i]), None, B, S, C, 1,
+             ptr(dirty), B * C * 2, LAYOUT, None, stream())
+
+    def f_fused():
+        i = nxt()
+        call("ctu_in_bwd_fused", dcode(DT), ptr(gs[i]), ptr(xs[i]), None, ptr(stats), ptr(sums), ptr(ys[i]), None, B, S, C, 1,
+             ptr(dirty), B * C * 2, LAYOUT, None, ptr(sync), stream())
     tag = f"{C}ch @{D}x{H}x{W} B{B}"
     report(f"in_apply       {tag}", timeit(f_apply), 0, 2 * nb)
     report(f"in_bwd_reduce  {tag}", timeit(f_red), 0, 2 * nb)
     report(f"in_bwd_apply   {tag}", timeit(f_bapply), 0, 3 * nb)
+    report(f"in_bwd pair    {tag}", timeit(f_pair), 0, 5 * nb)
+    if nb <= (32 << 20):
+        report(f"in_bwd fused   {tag}", timeit(f_fused), 0, 5 * nb)
 
 
 def halo(B, D, H, W, C, N, what):
@@ -160,7 +175,8 @@ CASES = {
     "inorm": lambda: [inorm(2, 96, 96, 96, 64), inorm(2, 48, 48, 96, 128), inorm(2, 48, 48, 96, 512), inorm(2, 24, 24, 48, 256),
                       inorm(2, 24, 24, 48, 1024), inorm(2, 48, 48, 96, 32)],
     "inorm_small": lambda: [inorm(2, 12, 12, 24, 128, sets=8), inorm(2, 12, 12, 24, 512, sets=8), inorm(2, 24, 24, 48, 64, sets=8),
-                            inorm(2, 24, 24, 48, 256, sets=8), inorm(2, 6, 6, 12, 256, sets=8), inorm(2, 6, 6, 12, 1024, sets=8)],
+                            inorm(2, 24, 24, 48, 256, sets=8), inorm(2, 6, 6, 12, 256, sets=8), inorm(2, 6, 6, 12, 1024, sets=8),
+                            inorm(2, 48, 48, 96, 32, sets=6)],
     "wgrad_debug": lambda: [(call("ctu_set_option", b"nt_debug", d), print("nt_debug =", d),
                              halo(2, 96, 96, 96, 64, 64, "wgrad"), halo(2, 48, 48, 96, 128, 128, "wgrad"),
                              halo(2, 24, 24, 48, 256, 256, "wgrad"), call("ctu_set_option", b"nt_debug", 0)) for d in (0, 4, 1, 5)],
