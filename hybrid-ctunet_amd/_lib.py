@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libctunet_hip.so")
-SOURCES = ["igemm.hip", "gemm_dma.hip", "conv3_halo.hip", "norm_elementwise.hip", "attention.hip", "attention_mfma.hip",
+SOURCES = ["igemm.hip", "gemm_dma.hip", "conv3_halo.hip", "norm_elementwise.hip", "ff_fused.hip", "attention.hip", "attention_mfma.hip",
            "loss_optim.hip", "infer.hip", "dropout.hip", "comm.hip", "plan.hip", "plan_dispatch.inc", "philox.h", "mma.h", "dma.h", "gemm_dma.h", "attn_common.h", "common.h"]
 
 CTU_F32, CTU_BF16 = 0, 1
@@ -76,6 +76,8 @@ _SIGS = {
     "ctu_attn_bwd_dropout": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(AttnGeom), _f32, C.c_uint64, C.c_uint64, _vp],
     "ctu_dropout": [_i32, _vp, _vp, _vp, _i64, _f32, C.c_uint64, C.c_uint64, _vp],
     "ctu_attn_dropout_mask": [_vp, _i32, _i32, _f32, C.c_uint64, C.c_uint64, _vp],
+    "ctu_ff_pack_w2": [_vp, _vp, _i32, _i32, _vp],
+    "ctu_ff_fwd": [_i32] + [_vp] * 11 + [_i64, _i32, _i32, _vp],
     "ctu_pwa_fwd": [_i32, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "ctu_pwa_bwd": [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "ctu_patchify": [_i32, _vp, _vp] + [_i32] * 7 + [_vp],

@@ -36,6 +36,8 @@ OPT = {"gelu2": 1,    # GELU backward inside the data-gradient GEMM of the Linea
                       # 1x1x1 as a plain GEMM over the output rows + ctu_add_strided2 (instead of the generic implicit GEMM)
        "nogres": 1,   # blocks with a conv + norm shortcut: that norm's backward reads the block's gradient and sign mask itself
                       # instead of a copy with the LeakyReLU slope applied, written by the main norm's backward (one tensor pass)
+       "ff1": 1,      # FeedForward forward of the 128-wide stages as ONE kernel (ctu_ff_fwd: LayerNorm, both products and GELU fused;
+                      # the backward pass re-derives LayerNorm(x) - the operand of W1's weight gradient - with one LayerNorm launch)
        "in1": 0}      # InstanceNorm backward of tensors up to IN_FUSED_BYTES as ONE launch (ctu_in_bwd_fused: reduce, meet at a counter, apply).
                       # Built, parity-tested and measured SLOWER: 21 - 57 us against 13 - 43 for the pair in kbench, 47.4 - 47.8 against
                       # 45.8 - 45.9 ms per step (profiles/r04_experiment_in_bwd_one_launch.log) - two launches of one stream pipeline, a
@@ -699,6 +701,7 @@ LNWS_FLOATS = 1024 * 2 * 2048   # CTU_LN_BWD_MAX_BLOCKS partial rows of up to 20
 class _Layer:
     params: Tuple[str, ...] = ()      # parameter names, in the order the Function receives them
     lin: Tuple[str, ...] = ()         # ... those that are Linear weights (forward operand = bf16 mirror [N][K])
+    packed: Tuple[Tuple[str, str], ...] = ()   # (slot suffix, parameter name): re-ordered copies of a weight the forward list reads
 
     def __init__(self, tag):
         self.tag = tag
@@ -780,17 +783,28 @@ class FFRes(_Layer):
         self.M, self.dim, self.hidden = M, dim, hidden
         self.params = ("g", "b", "w1", "b1", "w2", "b2")
         self.lin = ("w1", "w2")
+        # the forward as ONE kernel (ctu_ff_fwd) where its tile shapes fit: width 128, 256-row tiles, 64-unit hidden chunks
+        self.fused_fwd = bool(OPT["ff1"] and dim == 128 and hidden % 64 == 0 and 128 <= hidden <= 4096 and M % 256 == 0)
+        if self.fused_fwd:
+            self.packed = (("w2f", "w2"),)
 
     def declare(self, F, G):
         M, D, Hd = self.M, self.dim, self.hidden
         for nm, nb in (("h", M * D * 2), ("mr", M * 8), ("pre", M * Hd * 2), ("u", M * Hd * 2), ("y", M * D * 2)):
-            F.add(self.n(nm), nb)
+            if nm == "h" and self.fused_fwd:
+                G.add(self.n(nm), nb)     # LayerNorm(x) is never written forward: the backward pass re-derives it
+            else:
+                F.add(self.n(nm), nb)
         fused_gelu = D % 64 == 0 and Hd % 8 == 0 and OPT["gelu2"]
         for nm, nb in ((() if fused_gelu else (("gu", M * Hd * 2),)) + (("gpre", M * Hd * 2), ("gh", M * D * 2), ("gx", M * D * 2))):
             G.add(self.n(nm), nb)
 
     def fwd(self, R, need, x):
         n, M, D, Hd = self.n, self.M, self.dim, self.hidden
+        if self.fused_fwd:
+            R.call("ctu_ff_fwd", BF16, x, R[n("g")], R[n("b")], R[n("w1")], R[n("b1")], R[n("w2f")], R[n("b2")], R[n("y")], R[n("pre")],
+                   R[n("u")], R[n("mr")], M, D, Hd)
+            return R[n("y")]
         R.call("ctu_layernorm_fwd", BF16, x, R[n("g")], R[n("b")], R[n("h")], R[n("mr")], M, D)
         em_gemm(R, need, R[n("h")], R[n("w1")], R[n("u")], M, D, Hd, bias=R[n("b1")], act=1, pre_out=R[n("pre")])
         em_gemm(R, need, R[n("u")], R[n("w2")], R[n("y")], M, Hd, D, bias=R[n("b2")], residual=x)
@@ -806,6 +820,8 @@ class FFRes(_Layer):
             R.call("ctu_gelu_bwd", BF16, R[n("gu")], R[n("pre")], R[n("gpre")], M * Hd)
         _lin_wgrad(R, gy, R[n("u")], R[n("w2") + ".g"], R[n("b2") + ".g"], M, D, Hd, wg())
         _lin_dgrad(R, need, R[n("gpre")], R[n("w1")], self.t(R, "w1"), R[n("gh")], M, Hd, D)
+        if self.fused_fwd:   # h = LayerNorm(x) for W1's weight gradient (the same statistics land in mr again)
+            R.call("ctu_layernorm_fwd", BF16, x, R[n("g")], R[n("b")], R[n("h")], R[n("mr")], M, D)
         _lin_wgrad(R, R[n("gpre")], R[n("h")], R[n("w1") + ".g"], R[n("b1") + ".g"], M, Hd, D, wg())
         R.call("ctu_layernorm_bwd_add", BF16, R[n("gh")], x, R[n("g")], R[n("mr")], gy, R[n("gx")], R[n("g") + ".g"],
                R[n("b") + ".g"], R["lnws"], M, D)
@@ -869,12 +885,14 @@ class _PipePlan:
         self.is_lin = [p in ly.lin for ly in layers for p in ly.params]
         self.tnames = [ly.n(p) + ".t" for ly in layers for p, need in ly.needs_t().items() if need]
         self.t_index = [self.pnames.index(t[:-2]) for t in self.tnames]
+        self.xnames = [ly.n(sfx) for ly in layers for sfx, _ in ly.packed]          # re-ordered weight copies (forward list)
+        self.x_index = [self.pnames.index(ly.n(src)) for ly in layers for _, src in ly.packed]
         self.need = _Need()
         self.fwd = None
         self.bwd: Dict[tuple, object] = {}
 
     def record_fwd(self):
-        R = Recorder(["x", self.out_name] + self.pnames + list(self.FWD_WS) + self.F.slot_names())
+        R = Recorder(["x", self.out_name] + self.pnames + self.xnames + list(self.FWD_WS) + self.F.slot_names())
         self.F.bind(R)
         x = R["x"]
         for ly in self.layers:
@@ -908,8 +926,9 @@ class PipeFn(torch.autograd.Function):
         out = torch.empty(out_shape, dtype=x.dtype, device=dev)
         bufs = pl.F.alloc(dev)
         pv = [(ops._linear_weight(p, p, torch.bfloat16) if lin else p).data_ptr() for p, lin in zip(params, pl.is_lin)]
+        xv = [ops._packed(params[i], "ff_w2f", torch.bfloat16, lambda p=params[i]: _ff_w2_frag(p)).data_ptr() for i in pl.x_index]
         sid = L.stream()
-        vals = [x.data_ptr(), out.data_ptr()] + pv + [ops._splitk_workspace(dev, pl.need.skws).data_ptr()] + \
+        vals = [x.data_ptr(), out.data_ptr()] + pv + xv + [ops._splitk_workspace(dev, pl.need.skws).data_ptr()] + \
                [t.data_ptr() for t in bufs]
         pl.fwd.run(vals, (sid,))
         ctx.pl, ctx.bufs = pl, bufs
@@ -949,6 +968,14 @@ class PipeFn(torch.autograd.Function):
                 t[1]()
         ctx.bufs = None
         return (gx, None, None) + tuple(t[2] for t in targets)
+
+
+def _ff_w2_frag(w2):
+    """W2 [D][hidden] of a FeedForward in the fragment order ctu_ff_fwd reads (cached per parameter version by ops._packed)."""
+    m = ops._linear_weight(w2, w2, torch.bfloat16)   # (the optimizer's bf16 mirror is a flat view: shapes from the parameter)
+    out = torch.empty(w2.shape, dtype=torch.bfloat16, device=w2.device)
+    L.call("ctu_ff_pack_w2", m.data_ptr(), out.data_ptr(), w2.shape[0], w2.shape[1], L.stream())
+    return out
 
 
 _LNWS: Dict[tuple, torch.Tensor] = {}

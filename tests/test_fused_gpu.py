@@ -41,7 +41,7 @@ def _close(a, b, name, tol=2e-2, same=0.98):
     assert frac >= same, (name, "bit-equal fraction", frac)
 
 
-def _compare(block, xs_list, direct):
+def _compare(block, xs_list, direct, same_out=0.98, same_dx=0.5):
     import hybrid_ctunet_amd as H
     flat = H.FlatParams([p for p in block.parameters()]) if direct else None
     try:
@@ -52,9 +52,9 @@ def _compare(block, xs_list, direct):
             gy = torch.randn(shape, device="cuda").to(first.dtype)
             ref = _run(block, x, gy, False, flat)
             got = _run(block, x, gy, True, flat)
-            _close(got[0], ref[0], f"out[{rep}]")
+            _close(got[0], ref[0], f"out[{rep}]", same=same_out)
             for i, (a, b) in enumerate(zip(got[1], ref[1])):
-                _close(a, b, f"dx{i}[{rep}]", same=0.5)        # (split-K data gradients add with atomics)
+                _close(a, b, f"dx{i}[{rep}]", same=same_dx)    # (split-K data gradients add with atomics)
             for i, (a, b) in enumerate(zip(got[2], ref[2])):
                 assert (a is None) == (b is None)
                 if a is not None:
@@ -126,7 +126,8 @@ def test_vit_trunk_fused_equals_per_op(direct):
 
 
 @pytest.mark.parametrize("direct", [False, True])
-@pytest.mark.parametrize("ind,vol", [(0, (2, 6, 6, 12)), (1, (1, 12, 12, 24)), (2, (2, 12, 12, 24)), (3, (1, 12, 12, 24))])
+@pytest.mark.parametrize("ind,vol", [(0, (2, 6, 6, 12)), (1, (1, 12, 12, 24)), (2, (2, 12, 12, 24)), (3, (1, 12, 12, 24)),
+                                     (1, (2, 12, 12, 24))])   # (last: 6 912 rows of width 128 - the FeedForward forward as ONE kernel, ctu_ff_fwd)
 def test_up_attention_stage_fused_equals_per_op(ind, vol, direct):
     """One UpAttentionBlock stage: block attention + FF + grid attention + FF + PixelShuffle (stage 3: FF + FF + shuffle)."""
     from hybrid_ctunet_amd.networks import hybrid_CTUNet as N
@@ -147,8 +148,14 @@ def test_up_attention_stage_fused_equals_per_op(ind, vol, direct):
     m = Stage().cuda()
     xs = [torch.randn(*vol, c, device="cuda").to(torch.bfloat16) for _ in range(2)]
     assert F.up_stage_ok(xs[0], blk, ind, True)
-    _compare(m, xs, direct)
+    # a stage whose FeedForward forward runs as ctu_ff_fwd is no longer "the same kernels in the same order": LayerNorm statistics by
+    # a lane-local two-pass sum, GELU through a 1.5e-7 erf polynomial - the same values up to the last bf16 bit of some elements
+    ff_fused = c == 128 and (vol[0] * vol[1] * vol[2] * vol[3]) % 256 == 0 and F.OPT["ff1"]
+    _compare(m, xs, direct, same_out=0.9 if ff_fused else 0.98, same_dx=0.3 if ff_fused else 0.5)
     assert any(k[0] == "upstage" for k in F._cache)
+    if ff_fused:
+        pl = next(v for k, v in F._cache.items() if k[0] == "upstage" and k[2:7] == (*vol, c))
+        assert any(getattr(ly, "fused_fwd", False) for ly in pl.layers)
 
 
 @pytest.mark.parametrize("direct", [False, True])

@@ -979,3 +979,41 @@ def test_conv3d_halo_n_split_bit_equal(ops, case):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert torch.allclose(accs[0], accs[1], rtol=1e-5, atol=1e-5 * float(accs[0].abs().max()))
     del ws
+
+
+@pytest.mark.parametrize("M,Hd", [(512, 512), (2048, 128), (768, 1024)])
+def test_fused_feedforward_forward(ops, M, Hd):
+    """ctu_ff_fwd (LayerNorm -> W1 -> GELU -> W2 + residual in one kernel, hybrid_CTUNet.py:513-526) against float64 math on the
+    values the device holds: y, the stored pre-activation, gelu(pre) and the LayerNorm statistics."""
+    from hybrid_ctunet_amd._lib import call, dcode, ptr, stream
+    D = 128
+    dt = torch.bfloat16
+    x, xh = dev(rnd((M, D), 71, 2.0) + 0.3, dt)
+    g, gh = dev(1 + 0.2 * rnd((D,), 72), torch.float32)
+    b, bh = dev(0.1 * rnd((D,), 73), torch.float32)
+    w1, w1h = dev(rnd((Hd, D), 74, 1 / math.sqrt(D)), dt)
+    b1, b1h = dev(0.2 * rnd((Hd,), 75), torch.float32)
+    w2, w2h = dev(rnd((D, Hd), 76, 1 / math.sqrt(Hd)), dt)
+    b2, b2h = dev(0.2 * rnd((D,), 77), torch.float32)
+    w2f = torch.empty(D * Hd, device="cuda", dtype=dt)
+    call("ctu_ff_pack_w2", ptr(w2), ptr(w2f), D, Hd, stream())
+    y = torch.empty(M, D, device="cuda", dtype=dt)
+    pre = torch.empty(M, Hd, device="cuda", dtype=dt)
+    u = torch.empty(M, Hd, device="cuda", dtype=dt)
+    mr = torch.empty(M, 2, device="cuda")
+    for _ in range(2):   # (second call: the stage ring starts from the state the first left)
+        call("ctu_ff_fwd", dcode(dt), ptr(x), ptr(g), ptr(b), ptr(w1), ptr(b1), ptr(w2f), ptr(b2), ptr(y), ptr(pre), ptr(u), ptr(mr),
+             M, D, Hd, stream())
+    torch.cuda.synchronize()
+    mean = xh.mean(1, keepdim=True)
+    var = xh.var(1, unbiased=False, keepdim=True)
+    rstd = 1 / torch.sqrt(var + 1e-5)
+    h = ((xh - mean) * rstd * gh + bh).to(dt).double()       # the kernel rounds the normalised rows to bf16 (MFMA operand)
+    pre_ref = h @ w1h.t() + b1h
+    u_ref = F.gelu(pre_ref)
+    y_ref = xh + u_ref.to(dt).double() @ w2h.t() + b2h       # (and gelu(pre) likewise)
+    close(mr[:, 0], mean.squeeze(1), torch.float32, "mean")
+    close(mr[:, 1], rstd.squeeze(1), torch.float32, "rstd")
+    close(pre, pre_ref, dt, "pre")
+    close(u, u_ref, dt, "u")
+    close(y, y_ref, dt, "y")

@@ -151,7 +151,40 @@ def halo(B, D, H, W, C, N, what):
         report(f"conv3_halo wgrad {C}->{N} @{D}x{H}x{W} B{B}", us, flops, 2.0 * B * D * H * W * (C + N))
 
 
+def ff(M, Hd):
+    """Fused FeedForward forward (ctu_ff_fwd) against the three launches it replaces (LayerNorm, GEMM + GELU + pre, GEMM + residual)."""
+    D = 128
+    sets = 3
+    xs = [torch.randn(M, D, device=dev, dtype=DT) for _ in range(sets)]
+    g, b = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+    w1, b1 = torch.randn(Hd, D, device=dev, dtype=DT) * 0.09, torch.zeros(Hd, device=dev)
+    w2, b2 = torch.randn(D, Hd, device=dev, dtype=DT) * 0.04, torch.zeros(D, device=dev)
+    w2f = torch.empty(D * Hd, device=dev, dtype=DT)
+    call("ctu_ff_pack_w2", ptr(w2), ptr(w2f), D, Hd, stream())
+    ys = [torch.empty(M, D, device=dev, dtype=DT) for _ in range(sets)]
+    pres = [torch.empty(M, Hd, device=dev, dtype=DT) for _ in range(sets)]
+    us = [torch.empty(M, Hd, device=dev, dtype=DT) for _ in range(sets)]
+    hs = [torch.empty(M, D, device=dev, dtype=DT) for _ in range(sets)]
+    mr = torch.empty(M, 2, device=dev)
+    it = [0]
+
+    def fused():
+        i = it[0] = (it[0] + 1) % sets
+        call("ctu_ff_fwd", dcode(DT), ptr(xs[i]), ptr(g), ptr(b), ptr(w1), ptr(b1), ptr(w2f), ptr(b2), ptr(ys[i]), ptr(pres[i]), ptr(us[i]),
+             ptr(mr), M, D, Hd, stream())
+
+    def three():
+        i = it[0] = (it[0] + 1) % sets
+        call("ctu_layernorm_fwd", dcode(DT), ptr(xs[i]), ptr(g), ptr(b), ptr(hs[i]), ptr(mr), M, D, stream())
+        ops._plain_gemm(hs[i], w1, us[i], M, D, Hd, bias=b1, act=1, pre_out=pres[i])
+        ops._plain_gemm(us[i], w2, ys[i], M, Hd, D, bias=b2, residual=xs[i])
+    byt = 2.0 * M * (2 * D + 2 * Hd)
+    report(f"ff fused        M={M} D={D} Hd={Hd}", timeit(fused), 4.0 * M * D * Hd, byt)
+    report(f"ff three launches M={M} D={D} Hd={Hd}", timeit(three), 4.0 * M * D * Hd, byt)
+
+
 CASES = {
+    "ff": lambda: [ff(442368, 512), ff(55296, 512)],
     "tn_trunk": lambda: [tn(864, 3072, 768), tn(864, 768, 3072), tn(864, 2304, 768), tn(864, 768, 768)],
     "tn_big": lambda: [tn(442368, 512, 128), tn(442368, 128, 512), tn(442368, 384, 128), tn(442368, 128, 32),
                        tn(442368, 32, 128), tn(55296, 768, 256), tn(55296, 256, 64), tn(1769472, 16, 64),
@@ -193,6 +226,9 @@ CASES = {
                            halo(2, 24, 24, 48, 64, 64, "fwd"), halo(2, 12, 12, 24, 512, 512, "fwd"),
                            halo(2, 12, 12, 24, 128, 128, "wgrad"), halo(2, 6, 6, 12, 256, 256, "wgrad"),
                            halo(2, 24, 24, 48, 64, 64, "wgrad"), halo(2, 12, 12, 24, 512, 512, "wgrad")],
+    # tail quantisation: 1 728 bricks (3.375 rounds of 512 resident workgroups) against 1 536 (3 rounds) and 2 048 (4 rounds)
+    "halo_rounds": lambda: [halo(2, 48, 48, 96, 128, 128, "fwd"), halo(2, 48, 32, 128, 128, 128, "fwd"), halo(2, 64, 32, 128, 128, 128, "fwd"),
+                            halo(2, 48, 48, 96, 64, 64, "fwd"), halo(2, 96, 96, 96, 64, 64, "fwd")],
     "halo_wgrad": lambda: [halo(2, 96, 96, 96, 64, 64, "wgrad"), halo(2, 48, 48, 96, 128, 128, "wgrad"),
                            halo(2, 24, 24, 48, 256, 256, "wgrad"), halo(2, 48, 48, 96, 32, 32, "wgrad")],
 }
