@@ -58,7 +58,10 @@ def _compare(block, xs_list, direct, same_out=0.98, same_dx=0.5):
             for i, (a, b) in enumerate(zip(got[2], ref[2])):
                 assert (a is None) == (b is None)
                 if a is not None:
-                    _close(a, b, f"dw{i}[{rep}]", tol=1.5e-2, same=0.0)   # (fp32 atomics: the summation order is not fixed; bf16 operands)
+                    # weight gradients: the halo convolutions' partial panels are reduced in a fixed order (bit-equal); Linear /
+                    # 1x1x1 weight gradients of few work items add their row splits with fp32 atomics, whose order is free - the
+                    # bulk of the entries still agrees to the bit
+                    _close(a, b, f"dw{i}[{rep}]", tol=1.5e-2, same=0.25)
     finally:
         if flat is not None:
             flat.release()

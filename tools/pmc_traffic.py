@@ -38,10 +38,14 @@ rows.sort(reverse=True)
 print(f"per step: fetch {tf / steps / 1e9:.1f} GB, write {tw / steps / 1e9:.1f} GB")
 for t, k, n, fb, wb in rows[:14]:
     print(f"{k:62s} x{n / steps:6.1f}/step  fetch {fb / n / 1e6:8.1f} MB  write {wb / n / 1e6:8.1f} MB per launch  {t / steps / 1e9:6.2f} GB/step")
-try:
-    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "?"
-except OSError:
-    commit = "?"
+# the GPU box has no .git: the caller stamps the commit the snapshot was taken from (tools/final_measure.sh is started as
+# CTU_COMMIT=$(git rev-parse --short HEAD) gpurun ... with the variable expanded in the build container)
+commit = os.environ.get("CTU_COMMIT", "")
+if not commit:
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "?"
+    except OSError:
+        commit = "?"
 json.dump({"source_hash": source_hash(), "commit": commit, "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over python bench.py --serial --steps 2 "
                    "--warmup 1 (single stream: a launch's counters are that kernel's alone); FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md section HBM); bytes per launch "
                    "averaged over the launches of a step",
