@@ -592,12 +592,27 @@ class DataParallel(nn.Module):
         self._launched = [False] * len(self.buckets)
         self._works = []
         self._is_cuda = f.flat.is_cuda
+        self._wgrad_stream_before = None
         if (self.world > 1 or self._alone) and self._is_cuda and not os.environ.get("CTU_WGRAD_STREAM"):
-            # Measured with that rehearsal: one `side.wait_event(bucket event)` per bucket - the fence every bucket needs - costs
-            # 20 ms per step while the weight-gradient companion streams are in use (65 ms against 46; 47.8 with the companion
-            # streams off; the collective itself, the record and the stream count are not it: profiles/
-            # r03_bench_dp_rehearsal_world1.log).  Under data parallelism the weight gradients therefore stay on their layer's stream.
+            # HIP streams run on hardware queues that share FOUR hardware pipes (queue id mod 4), and a queue parked on a barrier
+            # packet - a stream waiting for an event - holds its pipe against the other queues on it.  The step alone uses four
+            # streams (main, branch, two weight-gradient companions: queues 4 - 7, one pipe each); the exchange stream is the
+            # fifth and lands on the pipe of one of them, where its bucket fences (one wait per bucket, each for work queued deep
+            # in the backward pass) stall that stream: 65 ms per step on main's pipe, 66 on the branch's, 74 / 83 on a companion's,
+            # against 47.6 with the companions off - and moved k queues along the pattern repeats with period 4
+            # (profiles/r04_five_streams.log).  So under data parallelism the step keeps to the pipes that are left: main, branch,
+            # exchange (+ RCCL's own stream); the weight gradients stay on their layer's stream.  release() puts the switch back.
+            self._wgrad_stream_before = ops.WGRAD_STREAM
             ops.WGRAD_STREAM = False
+        # measurement only (profiles/r04_five_streams.log): CTU_DP_QUEUE_SHIFT=k creates k throw-away streams first, so the exchange
+        # stream is handed the hardware queue k places further on
+        self._dummies = []
+        if self._is_cuda:
+            for _ in range(int(os.environ.get("CTU_DP_QUEUE_SHIFT", "0"))):
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=f.flat.device)
+                self._dummies.append(st)
         self._side = torch.cuda.Stream() if self._is_cuda else None
         self._seen = [False] * len(f.params)
         self._opt = None
@@ -693,6 +708,15 @@ class DataParallel(nn.Module):
         else:  # gloo moving device buffers (one-GPU rehearsals)
             sl.mul_(1.0 / self.world)
             dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def release(self):
+        """Detach from the gradient buffer and give back what the constructor changed process-wide (the weight-gradient
+        companion streams): a model that goes on training without the wrapper gets its four-stream schedule back."""
+        if self._on_ready in self.flat.listeners:
+            self.flat.listeners.remove(self._on_ready)
+        if self._wgrad_stream_before is not None:
+            ops.WGRAD_STREAM = self._wgrad_stream_before
+            self._wgrad_stream_before = None
 
     def finish(self):
         """Call after backward, before the optimizer step."""

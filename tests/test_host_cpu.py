@@ -315,3 +315,25 @@ def test_package_synthetic_batch_equals_the_oracle_generator():
     from oracle import ctunet_oracle as O
     a, b = H.synthetic_batch(1, size=(8, 8, 8), seed=1003), O.synthetic_batch(1, size=(8, 8, 8), seed=1003)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_data_parallel_release_restores_the_stream_switch():
+    """the wrapper switches the weight-gradient companion streams off process-wide while it exchanges
+    gradients (four hardware pipes: main, branch, exchange, RCCL's stream - train.DataParallel.__init__); release() must put the
+    caller's setting back and stop listening to the gradient buffer."""
+    from hybrid_ctunet_amd import ops
+    m = _Toy()
+    dp = train.DataParallel(m)
+    before = ops.WGRAD_STREAM
+    try:
+        ops.WGRAD_STREAM = False
+        dp._wgrad_stream_before = True          # what the constructor records on a GPU with world > 1
+        assert dp._on_ready in dp.flat.listeners
+        dp.release()
+        assert ops.WGRAD_STREAM is True and dp._wgrad_stream_before is None
+        assert dp._on_ready not in dp.flat.listeners
+        dp.release()                            # idempotent
+        assert ops.WGRAD_STREAM is True
+    finally:
+        ops.WGRAD_STREAM = before
+        dp.flat.release()
