@@ -172,6 +172,91 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, 
   }
 }
 
+// y = act((x - mean) * rstd + (x2 - mean2) * rstd2): the last norm of a block whose shortcut is conv + norm (resnet.py:122-124 with
+// downsample :196-199; hybrid_CTUNet.py:99-104) applied together with the shortcut's norm - the normalised shortcut is never
+// written and read back (two passes over the block's output tensor and one launch less per such block).  raw / raw2: UNSHIFTED fp64
+// sums from the producers' epilogues (NULL: stats / stats2 are inputs, e.g. after a ctu_in_stats pass); (mean, rstd) of both norms
+// are written for the backward pass; clear / clear2 name the accumulators of the PREVIOUS main / shortcut norm, zeroed here.
+template <typename T>
+__global__ __launch_bounds__(256) void in_apply_dual_kernel(const T* __restrict__ x, float* __restrict__ stats, const double* __restrict__ raw,
+                                                            const T* __restrict__ x2, float* __restrict__ stats2,
+                                                            const double* __restrict__ raw2, T* __restrict__ y, const int64_t S,
+                                                            const int C, const int act, uint8_t* __restrict__ mask,
+                                                            double* __restrict__ clear, const int clear_n,
+                                                            double* __restrict__ clear2, const int clear2_n) {
+  extern __shared__ float in_dual_lds[];   // mean[C] rstd[C] mean2[C] rstd2[C]
+  const int ncg = C >> 3;
+  const int b = blockIdx.y;
+  const int64_t nvec = S * ncg;
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  if (b == 0) {
+    if (clear) for (int64_t i = i0; i < clear_n; i += stride) clear[i] = 0.0;
+    if (clear2) for (int64_t i = i0; i < clear2_n; i += stride) clear2[i] = 0.0;
+  }
+  const double inv_s = 1.0 / (double)S;
+  for (int c = threadIdx.x; c < 2 * C; c += 256) {
+    const bool second = c >= C;
+    const int cc = second ? c - C : c;
+    const double* rw = second ? raw2 : raw;
+    float* st = second ? stats2 : stats;
+    const size_t o = ((size_t)b * C + cc) * 2;
+    float mf, rf;
+    if (rw) {
+      const double m = rw[o] * inv_s;
+      const double var = fmax(rw[o + 1] * inv_s - m * m, 0.0);
+      mf = (float)m;
+      rf = (float)(1.0 / sqrt(var + (double)NORM_EPS));
+      if (blockIdx.x == 0) {
+        st[o] = mf;
+        st[o + 1] = rf;
+      }
+    } else {
+      mf = st[o];
+      rf = st[o + 1];
+    }
+    in_dual_lds[(second ? 2 * C : 0) + cc] = mf;
+    in_dual_lds[(second ? 3 * C : C) + cc] = rf;
+  }
+  __syncthreads();
+  const int cg = (int)(i0 % ncg);
+  float mean[8], rstd[8], mean2[8], rstd2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mean[e] = in_dual_lds[cg * 8 + e];
+    rstd[e] = in_dual_lds[C + cg * 8 + e];
+    mean2[e] = in_dual_lds[2 * C + cg * 8 + e];
+    rstd2[e] = in_dual_lds[3 * C + cg * 8 + e];
+  }
+  const size_t base = (size_t)b * S * C;
+  x += base;
+  x2 += base;
+  y += base;
+  if (mask) mask += (size_t)b * nvec;
+  for (int64_t i = i0; i < nvec; i += stride) {
+    float v[8], w[8];
+    load8(x + i * 8, v);
+    load8(x2 + i * 8, w);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      // the shortcut's normalised value rounded to the activation type first: what the two-launch form stored and read back
+      const float rsd = (float)(T)((w[e] - mean2[e]) * rstd2[e]);
+      v[e] = (v[e] - mean[e]) * rstd[e] + rsd;
+    }
+    if (mask) {
+      unsigned bits = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bits |= (v[e] > 0.f ? 1u : 0u) << e;
+      mask[i] = (uint8_t)bits;
+    }
+    if (act) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * LRELU_SLOPE;
+    }
+    store8(y + i * 8, v);
+  }
+}
+
 // sums[b][c] = (sum g, sum g*xhat), g = dy * act'(y)
 template <typename T>
 __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
@@ -589,6 +674,27 @@ extern "C" int ctu_in_apply_acc(ctu_dtype dtype, const void* x, const double* ra
                                 void* y, int32_t B, int64_t S, int32_t C, int32_t act, int32_t y_layout,
                                 uint8_t* sign_mask, double* clear_ws, int32_t clear_n, ctu_stream_t stream) {
   return in_apply_impl(dtype, x, raw_acc, stats, residual, y, B, S, C, act, y_layout, sign_mask, clear_ws, clear_n, stream);
+}
+
+extern "C" int ctu_in_apply_dual(ctu_dtype dtype, const void* x, const double* raw_acc, float* stats, const void* x2,
+                                 const double* raw_acc2, float* stats2, void* y, int32_t B, int64_t S, int32_t C, int32_t act,
+                                 uint8_t* sign_mask, double* clear_ws, int32_t clear_n, double* clear_ws2, int32_t clear_n2,
+                                 ctu_stream_t stream) {
+  if (int rc = check_in(x, B, S, C)) return rc;
+  CTU_REQUIRE(x2 && stats && stats2 && y, "in_apply_dual: null pointer");
+  CTU_REQUIRE(clear_n >= 0 && (clear_n == 0 || clear_ws) && (clear_ws == nullptr || (clear_ws != raw_acc && clear_ws != raw_acc2)),
+              "in_apply_dual: bad clear workspace");
+  CTU_REQUIRE(clear_n2 >= 0 && (clear_n2 == 0 || clear_ws2) && (clear_ws2 == nullptr || (clear_ws2 != raw_acc && clear_ws2 != raw_acc2)),
+              "in_apply_dual: bad second clear workspace");
+  const dim3 grid(in_stream_grid(S, C, B), B);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)4 * C * sizeof(float);
+  CTU_DISPATCH(dtype,
+               hipLaunchKernelGGL(in_apply_dual_kernel<float>, grid, dim3(256), lds, s, (const float*)x, stats, raw_acc, (const float*)x2,
+                                  stats2, raw_acc2, (float*)y, S, C, act, sign_mask, clear_ws, clear_n, clear_ws2, clear_n2),
+               hipLaunchKernelGGL(in_apply_dual_kernel<bf16>, grid, dim3(256), lds, s, (const bf16*)x, stats, raw_acc, (const bf16*)x2,
+                                  stats2, raw_acc2, (bf16*)y, S, C, act, sign_mask, clear_ws, clear_n, clear_ws2, clear_n2));
+  return ctu_check_launch("in_apply_dual");
 }
 
 extern "C" int ctu_in_bwd_reduce(ctu_dtype dtype, const void* dy, const void* x, const void* y, const float* stats,

@@ -36,6 +36,8 @@ OPT = {"gelu2": 1,    # GELU backward inside the data-gradient GEMM of the Linea
                       # 1x1x1 as a plain GEMM over the output rows + ctu_add_strided2 (instead of the generic implicit GEMM)
        "nogres": 1,   # blocks with a conv + norm shortcut: that norm's backward reads the block's gradient and sign mask itself
                       # instead of a copy with the LeakyReLU slope applied, written by the main norm's backward (one tensor pass)
+       "dual": 1,     # blocks with a conv + norm shortcut: the block's last norm and the shortcut's norm applied by ONE kernel
+                      # (ctu_in_apply_dual) - the normalised shortcut tensor is never written and read back
        "ff1": 1,      # FeedForward forward of the 128-wide stages as ONE kernel (ctu_ff_fwd: LayerNorm, both products and GELU fused;
                       # the backward pass re-derives LayerNorm(x) - the operand of W1's weight gradient - with one LayerNorm launch)
        "in1": 0}      # InstanceNorm backward of tensors up to IN_FUSED_BYTES as ONE launch (ctu_in_bwd_fused: reduce, meet at a counter, apply).
@@ -70,7 +72,7 @@ def _flags():
 # per-(device, stream) state of the fused path
 # ---------------------------------------------------------------------------------------------------------------
 class _WS:
-    __slots__ = ("acc", "apar", "adirty", "sums", "par", "dirty_n", "insync")
+    __slots__ = ("acc", "apar", "adirty", "sums", "par", "dirty_n", "insync", "acc2", "apar2", "adirty2")
 
     def __init__(self, device):
         # InstanceNorm forward statistics: two fp64 accumulators alternate from norm to norm - a producer's epilogue sums into
@@ -78,6 +80,11 @@ class _WS:
         self.acc = [torch.zeros(1 << 14, dtype=torch.float64, device=device) for _ in range(2)]
         self.apar = 0       # index of the clean accumulator
         self.adirty = 0     # entries the last norm left dirty in the other one
+        # statistics of shortcut convolutions (ctu_in_apply_dual): a pair of their own, alternating from one dual norm to the next -
+        # the shortcut's sums have to survive the block's other norms, which go through `acc`
+        self.acc2 = [torch.zeros(1 << 14, dtype=torch.float64, device=device) for _ in range(2)]
+        self.apar2 = 0
+        self.adirty2 = 0
         self.sums = [torch.zeros(1 << 14, dtype=torch.float64, device=device) for _ in range(2)]  # IN backward sums, same scheme
         self.par = 0
         self.dirty_n = 0
@@ -203,6 +210,24 @@ class _InFwd:
         self.prev = B * C * 2
         if self.prev > STATS_MAX:
             raise RuntimeError(f"fused path: {B} x {C} InstanceNorm statistics exceed the fixed tables (the *_ok guards route such shapes to the per-op path)")
+
+
+def _emit_dual(nf, y, stats, y2, stats2, out, B, S, C, *, fused: bool, fused2: bool, act=1, mask=None):
+    """The block's last norm (k-th of the plan, producer sums in nf.acc() when `fused`) together with the shortcut's norm, whose
+    producer summed into R["ib0"] when `fused2` (else stats2 already holds (mean, rstd)).  Returns what the shortcut accumulators'
+    bookkeeping needs: 1 = ib0 was used and is dirty now, 0 = untouched (ib1 was cleared either way)."""
+    R = nf.R
+    acc, other = (R["ia0"], R["ia1"]) if nf.k % 2 == 0 else (R["ia1"], R["ia0"])
+    clear_n = R.ival("iadirty") if nf.k == 0 else nf.prev
+    if not fused:
+        R.call("ctu_in_stats", BF16, y, B, S, C, acc, stats)
+    R.call("ctu_in_apply_dual", BF16, y, acc if fused else None, stats, y2, R["ib0"] if fused2 else None, stats2, out, B, S, C, int(act),
+           mask, other, clear_n, R["ib1"], R.ival("ibdirty"))
+    nf.k += 1
+    nf.prev = B * C * 2
+    if nf.prev > STATS_MAX:
+        raise RuntimeError(f"fused path: {B} x {C} InstanceNorm statistics exceed the fixed tables")
+    return 1 if fused2 else 0
 
 
 class _InBwd:
@@ -389,17 +414,24 @@ def em_conv_wgrad(R, need, spec: ConvSpec, gy, x1, x2, gw, *, stream, x1_b16=0, 
 # ---------------------------------------------------------------------------------------------------------------
 # shared run-time plumbing
 # ---------------------------------------------------------------------------------------------------------------
-WS_NAMES = ("ia0", "ia1", "iadirty", "tnws", "skws")
+WS_NAMES = ("ia0", "ia1", "iadirty", "tnws", "skws", "ib0", "ib1", "ibdirty")
 BWD_WS_NAMES = ("s0", "s1", "dirty0", "tnws", "skws", "tnws1", "panel", "wgws", "insync")
 
 
-def _fwd_ws_values(device, sid, need: _Need, n_norms: int, last_n: int):
-    """Slot values of WS_NAMES for one forward replay, and the accumulator bookkeeping of its n_norms norms."""
+def _fwd_ws_values(device, sid, need: _Need, n_norms: int, last_n: int, dual=None):
+    """Slot values of WS_NAMES for one forward replay, and the accumulator bookkeeping of its n_norms norms.  dual: None = the plan
+    has no ctu_in_apply_dual, 1 = its shortcut sums went through ib0 (dirty now), 0 = a dual norm that left ib0 untouched."""
     w = _fws(device, sid)
     vals = [w.acc[w.apar].data_ptr(), w.acc[1 - w.apar].data_ptr(), w.adirty, ops._tn_workspace(device).data_ptr(),
-            ops._splitk_workspace(device, need.skws).data_ptr()]
+            ops._splitk_workspace(device, need.skws).data_ptr(), w.acc2[w.apar2].data_ptr(), w.acc2[1 - w.apar2].data_ptr(), w.adirty2]
     w.apar ^= n_norms & 1
     w.adirty = last_n
+    if dual is not None:
+        if dual:
+            w.apar2 ^= 1
+            w.adirty2 = last_n      # (the dual norm is the plan's last norm: same B x C)
+        else:
+            w.adirty2 = 0
     return vals
 
 
@@ -550,7 +582,14 @@ class _BneckPlan:
         need = self.need
         nf = _InFwd(R)
         res = R["x"]
-        if cd is not None:   # the shortcut branch first: its norm is done before conv3's sums need an accumulator
+        self.f_dual = None
+        dual = cd is not None and OPT["dual"]
+        f_sc = False
+        if dual:             # shortcut conv: its sums go to the shortcut accumulator and wait there for the block's last norm
+            f_sc = em_conv_fwd(R, need, cd, R["x"], None, R["wd"], R["yd"], acc=R["ib0"])
+            if not f_sc:
+                R.call("ctu_in_stats", BF16, R["yd"], B, cd.So, N4, R["ib0"], st[3])   # (leaves ib0 zeroed)
+        elif cd is not None:   # the shortcut branch first: its norm is done before conv3's sums need an accumulator
             f = em_conv_fwd(R, need, cd, R["x"], None, R["wd"], R["yd"], acc=nf.acc())
             nf.emit(R["yd"], st[3], R["rd"], B, cd.So, N4, fused=f, act=0)
             res = R["rd"]
@@ -559,7 +598,10 @@ class _BneckPlan:
         f = em_conv_fwd(R, need, c2, a1, None, R["w2"], y2, x1_b16=self.a1_b16, acc=nf.acc())
         nf.emit(y2, st[1], a2, B, c2.So, P, fused=f, act=1)
         f = em_conv_fwd(R, need, c3, a2, None, R["w3"], y3, acc=nf.acc())
-        nf.emit(y3, st[2], R["out"], B, c3.So, N4, fused=f, residual=res, act=1, mask=R["mask"])
+        if dual:
+            self.f_dual = _emit_dual(nf, y3, st[2], R["yd"], st[3], R["out"], B, c3.So, N4, fused=f, fused2=f_sc, act=1, mask=R["mask"])
+        else:
+            nf.emit(y3, st[2], R["out"], B, c3.So, N4, fused=f, residual=res, act=1, mask=R["mask"])
         self.f_norms, self.f_last = nf.k, nf.prev
         self.fwd = R.finish()
 
@@ -630,7 +672,7 @@ class BottleneckFn(torch.autograd.Function):
         dev = x.device
         out = torch.empty(pl.out_shape, dtype=x.dtype, device=dev)
         bufs = pl.fbufs.alloc(dev)
-        rd = torch.empty(pl.out_shape, dtype=x.dtype, device=dev) if wd is not None else None
+        rd = torch.empty(pl.out_shape, dtype=x.dtype, device=dev) if (wd is not None and pl.f_dual is None) else None
         w1f, _ = conv_weights(pl.c1, w1, dgrad=False)
         w2f, _ = conv_weights(pl.c2, w2, dgrad=False)
         w3f, _ = conv_weights(pl.c3, w3, dgrad=False)
@@ -638,7 +680,7 @@ class BottleneckFn(torch.autograd.Function):
         sid = L.stream()
         vals = [x.data_ptr(), out.data_ptr(), rd.data_ptr() if rd is not None else 0, w1f.data_ptr(),
                 w2f.data_ptr(), w3f.data_ptr(), wdf.data_ptr() if wdf is not None else 0] + \
-            _fwd_ws_values(dev, sid, pl.need, pl.f_norms, pl.f_last) + [t.data_ptr() for t in bufs]
+            _fwd_ws_values(dev, sid, pl.need, pl.f_norms, pl.f_last, pl.f_dual) + [t.data_ptr() for t in bufs]
         pl.fwd.run(vals, (sid,))
         ctx.pl = pl
         ctx.bufs = bufs
@@ -1138,14 +1180,24 @@ class _ResBlockPlan:
         need = self.need
         nf = _InFwd(R)
         res = R["x1"]
-        if c3 is not None:   # the shortcut branch first (see _BneckPlan.record_fwd)
+        self.f_dual = None
+        dual = c3 is not None and OPT["dual"]
+        f_sc = False
+        if dual:             # (see _BneckPlan.record_fwd)
+            f_sc = em_conv_fwd(R, need, c3, R["x1"], x2, R["w3"], R["y3"], acc=R["ib0"])
+            if not f_sc:
+                R.call("ctu_in_stats", BF16, R["y3"], B, S, N, R["ib0"], st[2])
+        elif c3 is not None:   # the shortcut branch first (see _BneckPlan.record_fwd)
             f = em_conv_fwd(R, need, c3, R["x1"], x2, R["w3"], R["y3"], acc=nf.acc())
             nf.emit(R["y3"], st[2], R["rd"], B, S, N, fused=f, act=0)
             res = R["rd"]
         f = em_conv_fwd(R, need, c1, R["x1"], x2, R["w1"], R["y1"], acc=nf.acc())
         nf.emit(R["y1"], st[0], R["a1"], B, S, N, fused=f, act=1, b16=self.a1_b16)
         f = em_conv_fwd(R, need, c2, R["a1"], None, R["w2"], R["y2"], x1_b16=self.a1_b16, acc=nf.acc())
-        nf.emit(R["y2"], st[1], R["out"], B, S, N, fused=f, residual=res, act=1, mask=R["mask"])
+        if dual:
+            self.f_dual = _emit_dual(nf, R["y2"], st[1], R["y3"], st[2], R["out"], B, S, N, fused=f, fused2=f_sc, act=1, mask=R["mask"])
+        else:
+            nf.emit(R["y2"], st[1], R["out"], B, S, N, fused=f, residual=res, act=1, mask=R["mask"])
         self.f_norms, self.f_last = nf.k, nf.prev
         self.fwd = R.finish()
 
@@ -1212,14 +1264,14 @@ class ResBlockFn(torch.autograd.Function):
         dev = x1.device
         out = torch.empty(pl.out_shape, dtype=x1.dtype, device=dev)
         bufs = pl.fbufs.alloc(dev)
-        rd = torch.empty(pl.out_shape, dtype=x1.dtype, device=dev) if w3 is not None else None
+        rd = torch.empty(pl.out_shape, dtype=x1.dtype, device=dev) if (w3 is not None and pl.f_dual is None) else None
         w1f = conv_weights(pl.c1, w1, dgrad=False)[0]
         w2f = conv_weights(pl.c2, w2, dgrad=False)[0]
         w3f = conv_weights(pl.c3, w3, dgrad=False)[0] if w3 is not None else None
         sid = L.stream()
         vals = [x1.data_ptr(), x2.data_ptr() if x2 is not None else 0, out.data_ptr(), rd.data_ptr() if rd is not None else 0,
                 w1f.data_ptr(), w2f.data_ptr(), w3f.data_ptr() if w3f is not None else 0] + \
-            _fwd_ws_values(dev, sid, pl.need, pl.f_norms, pl.f_last) + [t.data_ptr() for t in bufs]
+            _fwd_ws_values(dev, sid, pl.need, pl.f_norms, pl.f_last, pl.f_dual) + [t.data_ptr() for t in bufs]
         pl.fwd.run(vals, (sid,))
         ctx.pl, ctx.bufs, ctx.grad_stash = pl, bufs, grad_stash
         ctx.save_for_backward(x1, x2, w1, w2, w3)

@@ -236,6 +236,13 @@ int ctu_in_apply(ctu_dtype dtype, const void* x, const float* stats, const void*
 int ctu_in_apply_acc(ctu_dtype dtype, const void* x, const double* raw_acc, float* stats, const void* residual, void* y,
                      int32_t B, int64_t S, int32_t C, int32_t act, int32_t y_layout, uint8_t* sign_mask, double* clear_ws,
                      int32_t clear_n, ctu_stream_t stream);
+/* The last norm of a block whose shortcut is conv + norm, applied TOGETHER with the shortcut's norm (resnet.py:122-124 with the
+ * downsample of :196-199; hybrid_CTUNet.py:99-104): y = act((x - mean) * rstd + (x2 - mean2) * rstd2).  The normalised shortcut is
+ * never materialised.  raw_acc / raw_acc2 as in ctu_in_apply_acc (NULL: stats / stats2 are inputs); both (mean, rstd) tables are
+ * written; clear_ws / clear_ws2: the accumulators of the previous main / shortcut norm, zeroed here (may be NULL). */
+int ctu_in_apply_dual(ctu_dtype dtype, const void* x, const double* raw_acc, float* stats, const void* x2, const double* raw_acc2,
+                      float* stats2, void* y, int32_t B, int64_t S, int32_t C, int32_t act, uint8_t* sign_mask, double* clear_ws,
+                      int32_t clear_n, double* clear_ws2, int32_t clear_n2, ctu_stream_t stream);
 /* backward: g = dy * act'(y) (y may be NULL when no residual was added: then sign(y) == sign(xhat) and the third
  * input stream is skipped; with sign_mask from ctu_in_apply, y is not read either); sums[b][c] = (sum g, sum g*xhat), fp64, zero on entry;
  * dx = rstd*(g - s1/S - xhat*s2/S); dres = g when dres != NULL.  ctu_in_bwd_apply also zeroes clear_ws[0..clear_n)

@@ -58,10 +58,12 @@ def _compare(block, xs_list, direct, same_out=0.98, same_dx=0.5):
             for i, (a, b) in enumerate(zip(got[2], ref[2])):
                 assert (a is None) == (b is None)
                 if a is not None:
-                    # weight gradients: the halo convolutions' partial panels are reduced in a fixed order (bit-equal); Linear /
-                    # 1x1x1 weight gradients of few work items add their row splits with fp32 atomics, whose order is free - the
-                    # bulk of the entries still agrees to the bit
-                    _close(a, b, f"dw{i}[{rep}]", tol=1.5e-2, same=0.25)
+                    # weight gradients: no floor on the bit-equal fraction holds.  Linear / 1x1x1 weight gradients (TN GEMM) add their
+                    # row splits with fp32 atomics whose order is free (two runs of the SAME path agree on 0.07 % of the entries of a
+                    # 1x1x1 shortcut at 6 912 rows); the 3x3x3 halo ones are deterministic within a path, but the two paths reduce
+                    # in different orders (parameter-layout reduce here, panel + permute in the per-op path): 25 % equal.  The
+                    # value bound (1.5e-2 of the largest entry, bf16 operands) is the gate.
+                    _close(a, b, f"dw{i}[{rep}]", tol=1.5e-2, same=0.0)
     finally:
         if flat is not None:
             flat.release()
