@@ -240,9 +240,10 @@ __global__ __launch_bounds__(256) void in_apply_dual_kernel(const T* __restrict_
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       // the shortcut's normalised value rounded to the activation type first: what the two-launch form stored and read back
-      // and the sum without contraction to one fma: bit for bit what ctu_in_apply(residual) computes from the stored shortcut
+      // and the sum as ONE fma: what hipcc makes of in_apply_kernel's "(x - mean) * rstd" followed by "+= residual" - bit for bit
+      // what the two-launch form computes from the stored shortcut (tools/dualdbg.py)
       const float rsd = (float)(T)__fmul_rn(w[e] - mean2[e], rstd2[e]);
-      v[e] = __fadd_rn(__fmul_rn(v[e] - mean[e], rstd[e]), rsd);
+      v[e] = fmaf(v[e] - mean[e], rstd[e], rsd);
     }
     if (mask) {
       unsigned bits = 0;

@@ -36,8 +36,12 @@ OPT = {"gelu2": 1,    # GELU backward inside the data-gradient GEMM of the Linea
                       # 1x1x1 as a plain GEMM over the output rows + ctu_add_strided2 (instead of the generic implicit GEMM)
        "nogres": 1,   # blocks with a conv + norm shortcut: that norm's backward reads the block's gradient and sign mask itself
                       # instead of a copy with the LeakyReLU slope applied, written by the main norm's backward (one tensor pass)
-       "dual": 1,     # blocks with a conv + norm shortcut: the block's last norm and the shortcut's norm applied by ONE kernel
-                      # (ctu_in_apply_dual) - the normalised shortcut tensor is never written and read back
+       "dual": 0,     # blocks with a conv + norm shortcut: the block's last norm and the shortcut's norm applied by ONE kernel
+                      # (ctu_in_apply_dual) - the normalised shortcut tensor is never written and read back.  Built and tested (10
+                      # launches and 0.9 GB per step fewer; 45.08 / 45.25 against 45.32 / 45.25 ms per step: inside the noise).  Off:
+                      # its results differ from the two-launch form by one bf16 ulp in 0.003 % of the elements (tools/dualdbg.py), and
+                      # CUNet-101 amplifies that into a 1e-4 shift of the coarsest head's Dice term - across the gate that the
+                      # whole-model bf16 test holds at twice the reference's own bf16 error (profiles/r04_bench_ab_dual_norm.log)
        "ff1": 1,      # FeedForward forward of the 128-wide stages as ONE kernel (ctu_ff_fwd: LayerNorm, both products and GELU fused;
                       # the backward pass re-derives LayerNorm(x) - the operand of W1's weight gradient - with one LayerNorm launch)
        "in1": 0}      # InstanceNorm backward of tensors up to IN_FUSED_BYTES as ONE launch (ctu_in_bwd_fused: reduce, meet at a counter, apply).
