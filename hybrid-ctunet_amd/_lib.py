@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libctunet_hip.so")
-SOURCES = ["igemm.hip", "gemm_dma.hip", "conv3_halo.hip", "norm_elementwise.hip", "ff_fused.hip", "attention.hip", "attention_mfma.hip",
+SOURCES = ["igemm.hip", "gemm_dma.hip", "gemm_narrow.hip", "conv3_halo.hip", "norm_elementwise.hip", "ff_fused.hip", "attention.hip", "attention_mfma.hip",
            "loss_optim.hip", "infer.hip", "dropout.hip", "comm.hip", "plan.hip", "plan_dispatch.inc", "philox.h", "mma.h", "dma.h", "gemm_dma.h", "attn_common.h", "common.h"]
 
 CTU_F32, CTU_BF16 = 0, 1

@@ -715,9 +715,12 @@ static void launch_stream(const GemmNtArgs& p, hipStream_t stream) {
 }
 
 int ctu_option_nt_debug();
+bool gemm_nt_narrow_ok(const GemmNtArgs& p);                       // gemm_narrow.hip
+void launch_gemm_nt_narrow(const GemmNtArgs& p, hipStream_t stream);
 int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {
   p.debug = ctu_option_nt_debug();
   if (stream_ok(p)) { launch_stream(p, stream); return 0; }
+  if (gemm_nt_narrow_ok(p)) { launch_gemm_nt_narrow(p, stream); return 0; }
   // tile choice: the largest tile that still yields ~200 work items for the 512 resident workgroups; the 864-token
   // ViT trunk (M = 864) gets 64 x 64 tiles rather than a split K with its atomics and second pass
   const auto items = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };

@@ -1017,3 +1017,45 @@ def test_fused_feedforward_forward(ops, M, Hd):
     close(pre, pre_ref, dt, "pre")
     close(u, u_ref, dt, "u")
     close(y, y_ref, dt, "y")
+
+
+@pytest.mark.parametrize("M,K,N,variant", [(36864, 128, 32, "stats"), (36864, 128, 32, "plain"), (36864, 128, 32, "dgrad"),
+                                           (55296, 64, 64, "stats"), (32768, 32, 32, "plain"), (36864, 64, 32, "dgrad")])
+def test_narrow_output_gemm(ops, M, K, N, variant):
+    """gemm_nt_narrow (N = 32 / 64 output columns, M >= 32 768 rows: conv1 of the ResNet bottlenecks, resnet.py:96, and the data
+    gradient of their conv3, :100): result and fused InstanceNorm sums against float64, and bit-equal to the general LDS-DMA
+    kernel (ctu_set_option("route", 16384)) - the same products in the same order per accumulator."""
+    from hybrid_ctunet_amd import _lib
+    dt = torch.bfloat16
+    x, xh = dev(rnd((M, K), 91), dt)
+    B = 2
+    if variant == "dgrad":       # the forward weight of a K_fwd = N -> N_fwd = K layer, read reduction-major
+        w, wh = dev(rnd((K, N), 92, 1 / math.sqrt(K)), dt)
+        ref = xh @ wh
+    else:
+        w, wh = dev(rnd((N, K), 92, 1 / math.sqrt(K)), dt)
+        ref = xh @ wh.t()
+    outs, accs = [], []
+    for route in (0, 16384):
+        _lib.call("ctu_set_option", b"route", route)
+        try:
+            out = torch.empty(M, N, device="cuda", dtype=dt)
+            acc = torch.zeros(B * N * 2, device="cuda", dtype=torch.float64) if variant == "stats" else None
+            if variant == "dgrad":
+                ops._plain_gemm(x, w, out, M, K, N, w_kn=1)
+            else:
+                ops._plain_gemm(x, w, out, M, K, N, in_acc=acc, in_rows=M // B if acc is not None else 0)
+            torch.cuda.synchronize()
+            outs.append(out)
+            accs.append(acc)
+        finally:
+            _lib.call("ctu_set_option", b"route", 0)
+    close(outs[0], ref, dt, "out")
+    assert torch.equal(outs[0], outs[1])
+    if variant == "stats":
+        o = outs[0].double().cpu().view(B, M // B, N)      # (the sums are taken from the fp32 accumulators, before rounding)
+        s_ref = torch.stack([ref.view(B, M // B, N).sum(1), (ref.view(B, M // B, N) ** 2).sum(1)], -1).reshape(-1)
+        got = accs[0].cpu()
+        assert torch.allclose(got, s_ref, rtol=2e-3, atol=2e-3 * float(s_ref.abs().max())), (got[:4], s_ref[:4])
+        assert torch.allclose(accs[0], accs[1], rtol=1e-5, atol=1e-6 * float(accs[1].abs().max()))
+        del o
