@@ -1,5 +1,6 @@
 set -e
 R=$GRAFT_REPO_ROOT
+export CTU_COMMIT=${CTU_COMMIT:-?}
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_f --output-format csv -- python $R/bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $R/gpurun_out/pmc_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_w --output-format csv -- python $R/bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $R/gpurun_out/pmc_w.log 2>&1
