@@ -591,7 +591,12 @@ static unsigned in_stream_grid(int64_t S, int C, int B) {
   // at least four vectors per thread: its per-channel constants (mean, rstd, the two gradient means) cost as much as a
   // vector's arithmetic (2 x 48 x 48 x 96 x 32 ch backward apply: 35 us with one vector per thread against 16 us of HBM time)
   int64_t g = (S * ncg + 1023) / 1024;
-  const int64_t cap = 8192 / (B > 0 ? B : 1) > 0 ? 8192 / (B > 0 ? B : 1) : 1;
+  // 1 024 workgroups in all (four per CU), each walking its column group down the rows: alone as fast as the 8 192 of rounds 1-3
+  // (80.7 / 129.8 us against 81.9 / 132.0 at 64 ch @ 96^3), and in the overlapped step the longer-lived workgroups keep their CU slots
+  // against the other stream's halo workgroups: 45.70 / 45.71 against 45.91 / 45.89 ms per step.  2 048: 45.75; 512: 46.0 (the
+  // forward apply then loses a quarter of its bandwidth alone).  profiles/r04_experiment_in_grid.log
+  const int total = (ctu_option_route() & CTU_ROUTE_IN_GRID_8192) ? 8192 : 1024;
+  const int64_t cap = total / (B > 0 ? B : 1) > 0 ? total / (B > 0 ? B : 1) : 1;
   if (g > cap) g = cap;
   g = ((g + ncg - 1) / ncg) * ncg;
   return (unsigned)g;
