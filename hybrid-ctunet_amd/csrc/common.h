@@ -33,6 +33,7 @@ int ctu_option_route();         // A/B routing bits, see ctu_set_option "route"
 #define CTU_ROUTE_HALO_NSPLIT 4096 /* halo forward / data-gradient kernels with four n tiles: the n-split variant (wave-private weight rings, one barrier per half chunk) */
 #define CTU_ROUTE_NT_NO_NARROW 16384 /* narrow-output layers (N = 32 / 64) back on the general NT kernel */
 #define CTU_ROUTE_IN_GRID_8192 32768 /* InstanceNorm apply kernels: 8 192 workgroups in all (previous rule) instead of 1 024 */
+#define CTU_ROUTE_NT_NARROW_STATS 65536 /* narrow-output layers WITH fused InstanceNorm sums on the streaming kernel too (off: see gemm_narrow.hip) */
 #define CTU_ROUTE_HALO_GATHER_WAVE0 32 /* wave 0 gathers the halo alone (previous rule) instead of 7 + 3 x 4 pieces over the four waves */
 
 #define CTU_REQUIRE(cond, ...)      \

@@ -137,6 +137,11 @@ bool gemm_nt_narrow_ok(const GemmNtArgs& p) {
   return (p.N == 32 || p.N == 64) && p.K % 16 == 0 && (p.K == 32 || p.K == 64 || p.K == 128) && p.a2 == nullptr && p.C1 == p.K &&
          p.M % 32 == 0 && p.M >= 32768 && p.splitk <= 1 && !e.bias && e.act == 0 && !e.residual && !e.pre_out && !e.scatter &&
          e.n_split <= 0 && e.ldc == p.N && (!p.in_acc || (p.in_rows % 32 == 0 && p.M % p.in_rows == 0)) &&
+         // Layers that also sum InstanceNorm statistics stay on the general kernel unless asked for (route bit): the sums are the
+         // same numbers to fp32 rounding, but in another order, and CUNet-101's bf16 forward amplifies a changed last bit of a
+         // statistic into a 3e-4 shift of the coarsest head's Dice term - across the gate of the whole-model test, which is set at
+         // twice the reference's own bf16 error (0.87978 -> 0.88005 against 0.87968 / float64 0.87949)
+         (!p.in_acc || (ctu_option_route() & CTU_ROUTE_NT_NARROW_STATS)) &&
          !(ctu_option_route() & CTU_ROUTE_NT_NO_NARROW);
 }
 

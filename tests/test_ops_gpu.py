@@ -1036,7 +1036,7 @@ def test_narrow_output_gemm(ops, M, K, N, variant):
         w, wh = dev(rnd((N, K), 92, 1 / math.sqrt(K)), dt)
         ref = xh @ wh.t()
     outs, accs = [], []
-    for route in (0, 16384):
+    for route in (65536, 16384):    # (65536: the streaming kernel also where statistics are summed - off by default, gemm_narrow.hip)
         _lib.call("ctu_set_option", b"route", route)
         try:
             out = torch.empty(M, N, device="cuda", dtype=dt)
