@@ -54,25 +54,18 @@ __device__ __forceinline__ void store16_asm(void* p, const u32x4& v) {
   asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
-// GELU (erf form, nn.GELU's default) without branches and with ONE transcendental: Abramowitz & Stegun 7.1.28,
-// 1 - erf(x) = (1 + a1 x + ... + a6 x^6)^-16 for x >= 0 (|error| <= 3e-7, far below the bf16 rounding of the result): six FMAs, four
-// squarings, one v_rcp_f32.  (History: the ocml erff costs ~38 vector instructions per value and a divergent branch - 1 240 vector
-// instructions per 32 MFMAs in this kernel; A&S 7.1.26 needs v_exp_f32 AND a reciprocal, and transcendentals issue at a quarter of
-// the rate; __frcp_rn is a full IEEE division, 6 instructions.)  For v < 0 the small factor 1 - erf(|v| / sqrt 2) is used
-// directly (no cancellation in the tail).
+// GELU (erf form, nn.GELU's default) without branches: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the
+// bf16 rounding of the result); the ocml erff costs ~38 vector instructions per value and a divergent branch - 1 240 vector
+// instructions per 32 MFMAs in this kernel, far more than the 32 MFMAs can hide.
+// For v < 0 the small factor 1 - erf(|v| / sqrt 2) is used directly (no cancellation in the tail).
 __device__ __forceinline__ float gelu_fast(float v) {
   const float ax = fabsf(v) * 0.70710678118654752440f;
-  float d = fmaf(0.0000430638f, ax, 0.0002765672f);
-  d = fmaf(d, ax, 0.0001520143f);
-  d = fmaf(d, ax, 0.0092705272f);
-  d = fmaf(d, ax, 0.0422820123f);
-  d = fmaf(d, ax, 0.0705230784f);
-  d = fmaf(d, ax, 1.0f);
-  d *= d;
-  d *= d;
-  d *= d;
-  d *= d;                                        // (1 + ...)^16; overflows to inf beyond |v| ~ 25: 1 / inf = 0, erf = 1
-  const float pe = __builtin_amdgcn_rcpf(d);     // = 1 - erf(ax)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));   // (v_rcp_f32: 1 ulp; __frcp_rn is a full IEEE division, 6 instructions)
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float pe = poly * t * __expf(-ax * ax);   // = 1 - erf(ax)
   const float half = 0.5f * v * pe;
   return v < 0.f ? half : v - half;
 }
