@@ -183,7 +183,16 @@ def ff(M, Hd):
     report(f"ff three launches M={M} D={D} Hd={Hd}", timeit(three), 4.0 * M * D * Hd, byt)
 
 
+def colsum(M, N, scaled):
+    x = torch.randn(M, N, device=dev, dtype=DT)
+    rs = torch.randn(M, device=dev, dtype=DT) if scaled else None
+    out = torch.zeros(N, device=dev)
+    us = timeit(lambda: call("ctu_colsum", dcode(DT), ptr(x), ptr(rs), M, N, N, ptr(out), stream()))
+    report(f"colsum M={M} N={N} scaled={scaled}", us, 0, 2.0 * M * N)
+
+
 CASES = {
+    "colsum": lambda: [colsum(1769472, 64, True), colsum(1769472, 64, True), colsum(1769472, 16, False), colsum(442368, 128, False)],
     "ff": lambda: [ff(442368, 512), ff(55296, 512)],
     "tn_trunk": lambda: [tn(864, 3072, 768), tn(864, 768, 3072), tn(864, 2304, 768), tn(864, 768, 768)],
     "tn_big": lambda: [tn(442368, 512, 128), tn(442368, 128, 512), tn(442368, 384, 128), tn(442368, 128, 32),
