@@ -1197,12 +1197,44 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, co
     }
   }
 }
+// few rows, many columns (the gradient of a parameter broadcast over the batch: position embedding, vit.py:118-126 - 2 rows of 331 776
+// columns): one thread per 8-column group walks the rows and owns its outputs - no LDS, no atomics.  (Through colsum_kernel this was
+// ONE workgroup looping over 41 472 column groups: 280 us for 1.3 MB.)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const T* __restrict__ x, const T* __restrict__ row_scale, const int64_t M,
+                                                          const int N, const int ld, float* __restrict__ out) {
+  const int cg = blockIdx.x * 256 + threadIdx.x;
+  if (cg >= (N >> 3)) return;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int64_t m = 0; m < M; ++m) {
+    float v[8];
+    load8(x + (size_t)m * ld + cg * 8, v);
+    const float sc = row_scale ? (float)row_scale[m] : 1.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = fmaf(sc, v[e], acc[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) out[cg * 8 + e] += acc[e];
+}
+
 extern "C" int ctu_colsum(ctu_dtype dtype, const void* x, const void* row_scale, int64_t M, int32_t N, int32_t ld,
                           float* out, ctu_stream_t stream) {
   CTU_REQUIRE(x && out && M > 0 && N > 0 && N % 8 == 0 && ld >= N && ld % 8 == 0, "colsum: bad args");
+  if (M <= 64 && N >= 2048) {
+    const unsigned wgrid = (unsigned)((N / 8 + 255) / 256);
+    hipStream_t ws = (hipStream_t)stream;
+    CTU_DISPATCH(dtype,
+                 hipLaunchKernelGGL(colsum_wide_kernel<float>, dim3(wgrid), dim3(256), 0, ws, (const float*)x, (const float*)row_scale, M, N,
+                                    ld, out),
+                 hipLaunchKernelGGL(colsum_wide_kernel<bf16>, dim3(wgrid), dim3(256), 0, ws, (const bf16*)x, (const bf16*)row_scale, M, N,
+                                    ld, out));
+    return ctu_check_launch("colsum");
+  }
   // every workgroup ends with N atomics on the same N addresses: a narrow matrix takes fewer, longer workgroups
   // (1024 workgroups x 16 columns spent 200 us of a 265 us pass queueing on 16 addresses)
-  const int64_t blocks = N <= 16 ? 256 : (N <= 64 ? 512 : 1024);
+  const int64_t blocks = N <= 64 ? 256 : 1024;
   int64_t rows = (M + blocks - 1) / blocks;
   if (rows < 64) rows = 64;
   const unsigned grid = (unsigned)((M + rows - 1) / rows);
@@ -1598,8 +1630,23 @@ extern "C" int ctu_pwa_bwd(ctu_dtype dtype, const void* qkv1, const void* qkv2, 
 // One thread writes a whole row of P (kpad / 8 vectors): the row's output coordinate is decomposed once, the taps advance by
 // increment with carry, the image reads (L2-resident) of neighbouring rows overlap.  (One thread per 16-byte vector paid nine
 // integer divisions for eight 2-byte reads: 164 us for the 340 MB of the stem's patch matrix, 3x its store time.)
+// division of a value below 2^31 by a launch constant: q = (n * ceil(2^(32 + s) / d)) >> (32 + s), s = ceil(log2 d) (exact for
+// n < 2^31; four instructions instead of the ~40 of a 32-bit division - the kernel spent more on its three divisions per 16-byte
+// store than on the store: 144 us per launch for 113 / 340 MB)
+struct FastDiv { unsigned long long m; int s; int d; };
+static FastDiv fast_div(int d) {
+  FastDiv f;
+  f.d = d;
+  f.s = 0;
+  while ((1ll << f.s) < d) ++f.s;
+  f.m = (((unsigned long long)1 << (32 + f.s)) + (unsigned long long)d - 1) / (unsigned long long)d;
+  return f;
+}
+__device__ __forceinline__ int fdiv(unsigned n, const FastDiv& f) { return (int)(((unsigned long long)n * f.m) >> (32 + f.s)); }
+
 __global__ __launch_bounds__(256) void im2col_cin1_kernel(const bf16* __restrict__ x, bf16* __restrict__ P, const ctu_geom g,
-                                                          const int taps, const int kpad, const int64_t M) {
+                                                          const int taps, const int kpad, const int64_t M, const FastDiv dkg,
+                                                          const FastDiv dwo, const FastDiv dho, const FastDiv ddo) {
   const int kg = kpad >> 3;  // 8-tap groups per row
   // lanes of a wave take CONSECUTIVE vectors of P (coalesced 16-byte stores): vector i = (row, group); a thread keeps one group
   // index and walks down the rows, so only the row index is decomposed per iteration (three divisions)
@@ -1612,12 +1659,15 @@ __global__ __launch_bounds__(256) void im2col_cin1_kernel(const bf16* __restrict
   int th0 = tq % g.kh, td0 = tq / g.kh;
   const int64_t total = M * kg;
   for (int64_t i = i0; i < total; i += stride) {
-    const int64_t m = i / kg;
+    const int64_t m = i < (1ll << 31) ? (int64_t)fdiv((unsigned)i, dkg) : i / kg;
     int t = (int)m;
-    const int ow = t % g.Wo; t /= g.Wo;
-    const int oh = t % g.Ho; t /= g.Ho;
-    const int od = t % g.Do;
-    const int b = t / g.Do;
+    int q = fdiv((unsigned)t, dwo);
+    const int ow = t - q * g.Wo; t = q;
+    q = fdiv((unsigned)t, dho);
+    const int oh = t - q * g.Ho; t = q;
+    q = fdiv((unsigned)t, ddo);
+    const int od = t - q * g.Do;
+    const int b = q;
     bf16x8 v;
     int tw = tw0, th = th0, td = td0;
     const int bd = od * g.sd - g.pd, bh = oh * g.sh - g.ph, bw = ow * g.sw - g.pw;
@@ -1648,6 +1698,6 @@ extern "C" int ctu_im2col_cin1(const void* x, void* P, const ctu_geom* g, int32_
   if (grid > 16384) grid = 16384;
   grid = (grid + kg - 1) / kg * kg;   // grid x 256 a multiple of kg: a thread keeps its tap group
   hipLaunchKernelGGL(im2col_cin1_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16*)x, (bf16*)P, *g, taps, kpad, M);
+                     (const bf16*)x, (bf16*)P, *g, taps, kpad, M, fast_div(kg), fast_div(g->Wo), fast_div(g->Ho), fast_div(g->Do));
   return ctu_check_launch("im2col_cin1");
 }
