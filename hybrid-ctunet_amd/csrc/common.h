@@ -34,6 +34,7 @@ int ctu_option_route();         // A/B routing bits, see ctu_set_option "route"
 #define CTU_ROUTE_NT_NO_NARROW 16384 /* narrow-output layers (N = 32 / 64) back on the general NT kernel */
 #define CTU_ROUTE_IN_GRID_8192 32768 /* InstanceNorm apply kernels: 8 192 workgroups in all (previous rule) instead of 1 024 */
 #define CTU_ROUTE_NT_NARROW_STATS 65536 /* narrow-output layers WITH fused InstanceNorm sums on the streaming kernel too (off: see gemm_narrow.hip) */
+#define CTU_ROUTE_NO_GATHER_GEMM 131072 /* in-grid strided taps (patch / transposed convolutions, 1x1x1 s2) on the generic kernels, not the LDS-DMA GEMMs */
 #define CTU_ROUTE_HALO_GATHER_WAVE0 32 /* wave 0 gathers the halo alone (previous rule) instead of 7 + 3 x 4 pieces over the four waves */
 
 #define CTU_REQUIRE(cond, ...)      \
@@ -100,6 +101,19 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+
+// Division of a value below 2^31 by a launch constant: q = (n * ceil(2^(32 + s) / d)) >> (32 + s), s = ceil(log2 d): exact
+// for n < 2^31, four instructions instead of the ~40 of a 32-bit division.
+struct FastDiv { unsigned long long m; int s; int d; };
+static inline FastDiv fast_div(int d) {
+  FastDiv f;
+  f.d = d;
+  f.s = 0;
+  while ((1ll << f.s) < d) ++f.s;
+  f.m = (((unsigned long long)1 << (32 + f.s)) + (unsigned long long)d - 1) / (unsigned long long)d;
+  return f;
+}
+__device__ __forceinline__ int fdiv(unsigned n, const FastDiv& f) { return (int)(((unsigned long long)n * f.m) >> (32 + f.s)); }
 
 static inline unsigned grid_for(int64_t work_items, int block, int64_t cap = 8192) {
   int64_t g = (work_items + block - 1) / block;

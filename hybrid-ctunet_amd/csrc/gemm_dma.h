@@ -2,8 +2,34 @@
 #pragma once
 #include "common.h"
 
+// Gathered operand of a convolution whose taps never leave the grid (no padding, (Do - 1) s + k <= Di per axis: the
+// kernel == stride patch convolutions and transposed-convolution gradients, the 1x1x1 stride-2 shortcuts).  Row m of the
+// row space [B][Do][Ho][Wo] and tap t read source row base(m) + tapoff[t] of the gathered tensor [B*Di*Hi*Wi][C]:
+// base(m) = b sB + od sD + oh sH + ow sW, separable from the tap - the DMA kernels add a per-lane row base to the
+// wave-uniform tap address, nothing else changes.  taps <= 8.
+struct GatherGeom {
+  int on;
+  int C;                  // channels = row length of the gathered tensor
+  int taps;
+  int sB, sD, sH, sW;     // source-row steps: Di*Hi*Wi, sd*Hi*Wi, sh*Wi, sw
+  int tapoff[8];          // (td*Hi + th)*Wi + tw
+  FastDiv dWo, dHo, dDo;  // decode of m
+  FastDiv dKpt;           // NT kernel: 64-deep k steps per tap (filled by the launcher)
+};
+__device__ __forceinline__ int gather_base(const GatherGeom& g, int m) {
+  int q = fdiv((unsigned)m, g.dWo);
+  const int ow = m - q * g.dWo.d; m = q;
+  q = fdiv((unsigned)m, g.dHo);
+  const int oh = m - q * g.dHo.d; m = q;
+  q = fdiv((unsigned)m, g.dDo);
+  const int od = m - q * g.dDo.d;
+  return q * g.sB + od * g.sD + oh * g.sH + ow * g.sW;
+}
+// fills `gg` when `g` is such a geometry (mode 0) with C1 % 64 == 0 channels and no second source
+bool gather_geom_from(const ctu_geom* g, GatherGeom& gg);
+
 struct GemmNtArgs {
-  const bf16* a1;  // [M][C1]
+  const bf16* a1;  // [M][C1]; with ga.on the gathered tensor [B*Di*Hi*Wi][C], K = taps * C and w = [taps][N][C]
   const bf16* a2;  // [M][C2] (k >= C1), or NULL
   const bf16* w;   // [N][K], K = C1 + C2; or, with w_kn, [K][N] (reduction-major)
   int w_kn;
@@ -16,6 +42,7 @@ struct GemmNtArgs {
   int in_rows;     // rows per batch item (a multiple of 128: no tile straddles two items)
   int tiles_m, tiles_n, ksteps, ks_per_split, nwork;  // filled by the launcher
   int debug;       // measurement hook (ctu_set_option "nt_debug"): 1 = no output stores, 2 = no operand DMA
+  GatherGeom ga;   // ga.on: A rows are gathered (see GatherGeom)
 };
 
 // returns 0 on launch, -1 if the shape is out of range (caller falls back to the generic kernel)
@@ -30,6 +57,7 @@ struct GemmTnArgs {
   int ldp, M, N, C, C1, C2;
   float* part;      // filled by the launcher: partial panels [splits][N][C] for the two-stage reduction, or NULL
   int tiles_n, tiles_c, splits, rows_per_split;
+  GatherGeom ga;    // ga.on: Q rows are gathered, C = taps * ga.C columns (column t*ga.C + c = tap t, channel c) and dw = [taps][N][ga.C]
 };
 
 // returns 0 on launch (a.part / a.splits tell the caller whether a reduction pass over `ws` must follow), -1 if out of range

@@ -78,9 +78,10 @@ template <int IPW, int MAXA, int EXTRA = 0> __device__ __forceinline__ void wait
 // ds_read -> MFMA chains interleave (with one wave per SIMD a 64 x 64 tile is a chain of exposed LDS latencies: 2.2 k
 // cycles per 128-deep stage for 256 cycles of MFMA); at the end of a tile group 1 hands its accumulators to group 0
 // through LDS.  No split-K atomics, no second pass.
-template <int BM, int BN, int R, bool BT, int BK = 64, int KG = 1>
+template <int BM, int BN, int R, bool BT, int BK = 64, int KG = 1, bool GA = false>
 __global__ __launch_bounds__(256 * KG, (KG == 2 || R * (BM + BN) * BK * 2 > 76 * 1024) ? 1 : 2) void gemm_nt_dma_kernel(const GemmNtArgs p) {
   static_assert(BK == 64 || BK == 128 || (BK == 32 && !BT), "stage depth");
+  static_assert(!GA || (BK == 64 && !BT && KG == 1), "gathered A operand: 64-deep stages, row-major weight panels");
   constexpr int ROWB = BK * 2;         // bytes of a tile row in LDS
   constexpr int SPR = BK / 8;          // 16-B slots per row
   constexpr int RPI = 1024 / ROWB;     // tile rows per DMA wave-instruction
@@ -146,8 +147,31 @@ __global__ __launch_bounds__(256 * KG, (KG == 2 || R * (BM + BN) * BK * 2 > 76 *
     }
   }
 
+  // gathered A operand (GatherGeom): source row of each of this lane's tile rows, re-derived when the m tile changes
+  int abase[APW], abase_m0 = -1;
   auto issue = [&](const WorkItem& it, int ks, int st) {
     if (p.debug & 2) return;
+    if constexpr (GA) {
+      const int C = p.ga.C;
+      const int mrem = p.M - 1 - it.m0;
+      if (it.m0 != abase_m0) {
+#pragma unroll
+        for (int j = 0; j < APW; ++j) abase[j] = gather_base(p.ga, it.m0 + min(arow[j], mrem));
+        abase_m0 = it.m0;
+      }
+      const int t = fdiv((unsigned)ks, p.ga.dKpt);   // k steps [t kpt, (t + 1) kpt) belong to tap t
+      const int kin = (ks - t * p.ga.dKpt.d) * BK;
+      unsigned char* sa = smem + st * STAGE;
+      unsigned va[APW], vb[BPW];
+#pragma unroll
+      for (int j = 0; j < APW; ++j) va[j] = ((unsigned)abase[j] * (unsigned)C + (unsigned)(aslot[j] * 8)) * 2u;
+      dma16_groupN<APW, 1024>(p.a1 + (size_t)p.ga.tapoff[t] * C + kin, va, sa + APW * wave * 1024);
+      const int nrem = p.N - 1 - it.n0;
+#pragma unroll
+      for (int j = 0; j < BPW; ++j) vb[j] = (unsigned)((min(brow[j], nrem) * C + bslot[j] * 8) * 2);
+      dma16_groupN<BPW, 1024>(p.w + ((size_t)t * p.N + it.n0) * C + kin, vb, sa + A_BYTES + BPW * wave * 1024);
+      return;
+    }
     const int k0 = ks * BK;
     const bool first = k0 < p.C1;
     const bf16* a = first ? p.a1 : p.a2;
@@ -714,13 +738,40 @@ static void launch_stream(const GemmNtArgs& p, hipStream_t stream) {
 #undef CTU_STREAM
 }
 
+bool gather_geom_from(const ctu_geom* g, GatherGeom& gg) {
+  gg.on = 0;
+  const int taps = g->kd * g->kh * g->kw;
+  const int64_t src_rows = (int64_t)g->B * g->Di * g->Hi * g->Wi;
+  if (g->mode != 0 || g->C2 != 0 || g->C1 % 64 != 0 || taps < 1 || taps > 8 || g->pd || g->ph || g->pw ||
+      (g->Do - 1) * g->sd + g->kd > g->Di || (g->Ho - 1) * g->sh + g->kh > g->Hi || (g->Wo - 1) * g->sw + g->kw > g->Wi ||
+      src_rows * g->C1 * 2 >= (1ll << 32) || (int64_t)g->B * g->Do * g->Ho * g->Wo >= (1ll << 31))
+    return false;
+  gg.on = 1;
+  gg.C = g->C1;
+  gg.taps = taps;
+  gg.sB = g->Di * g->Hi * g->Wi;
+  gg.sD = g->sd * g->Hi * g->Wi;
+  gg.sH = g->sh * g->Wi;
+  gg.sW = g->sw;
+  for (int t = 0; t < 8; ++t) gg.tapoff[t] = 0;
+  for (int td = 0, t = 0; td < g->kd; ++td)
+    for (int th = 0; th < g->kh; ++th)
+      for (int tw = 0; tw < g->kw; ++tw, ++t) gg.tapoff[t] = (td * g->Hi + th) * g->Wi + tw;
+  gg.dWo = fast_div(g->Wo);
+  gg.dHo = fast_div(g->Ho);
+  gg.dDo = fast_div(g->Do);
+  gg.dKpt = fast_div(g->C1 / 64);
+  return true;
+}
+
 int ctu_option_nt_debug();
 bool gemm_nt_narrow_ok(const GemmNtArgs& p);                       // gemm_narrow.hip
 void launch_gemm_nt_narrow(const GemmNtArgs& p, hipStream_t stream);
 int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {
   p.debug = ctu_option_nt_debug();
-  if (stream_ok(p)) { launch_stream(p, stream); return 0; }
-  if (gemm_nt_narrow_ok(p)) { launch_gemm_nt_narrow(p, stream); return 0; }
+  if (p.ga.on && (p.w_kn || p.a2 || p.ga.C % 64 != 0 || p.K != p.ga.taps * p.ga.C)) return -1;
+  if (!p.ga.on && stream_ok(p)) { launch_stream(p, stream); return 0; }
+  if (!p.ga.on && gemm_nt_narrow_ok(p)) { launch_gemm_nt_narrow(p, stream); return 0; }
   // tile choice: the largest tile that still yields ~200 work items for the 512 resident workgroups; the 864-token
   // ViT trunk (M = 864) gets 64 x 64 tiles rather than a split K with its atomics and second pass
   const auto items = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
@@ -735,7 +786,8 @@ int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {
   // 64 x 64 tiles (the 864-token ViT trunk: a handful of MFMAs per 64-deep stage, the stage hand-over dominates) take
   // 128-deep stages when K allows: half the barriers and waits per tile, 8 MFMAs per wave between them
   const bool bk128 = !bk32 && BM == 64 && BN == 64 && p.K % 128 == 0 && p.K >= 512 && (!p.a2 || p.C1 % 128 == 0) &&
-                     !(ctu_option_route() & CTU_ROUTE_NT_NO_BK128);
+                     !p.ga.on && !(ctu_option_route() & CTU_ROUTE_NT_NO_BK128);
+  if (p.ga.on) p.ga.dKpt = fast_div(p.ga.C / 64);
   p.ksteps = p.K / (bk32 ? 32 : bk128 ? 128 : 64);
   if (p.splitk > p.ksteps) p.splitk = p.ksteps;
   if (p.splitk < 1) p.splitk = 1;
@@ -750,7 +802,12 @@ int launch_gemm_nt_dma(GemmNtArgs& p, hipStream_t stream) {
   const int cols = p.tiles_n * p.splitk;
   const int grid = p.nwork < 512 ? p.nwork : (cols >= 512 ? cols : 512 / cols * cols);
   const dim3 g(grid), b(256);
-  if (bk32) {
+  if (p.ga.on) {
+    if (BM == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 64, 4, false, 64, 1, true>), g, b, 0, stream, p);
+    else if (BN == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 64, 2, false, 64, 1, true>), g, b, 0, stream, p);
+    else if (one_per_cu) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128, 3, false, 64, 1, true>), g, b, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128, 2, false, 64, 1, true>), g, b, 0, stream, p);
+  } else if (bk32) {
     if (p.w_kn) return -1;
     if (BN == 64) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 64, 3, false, 32>), g, b, 0, stream, p);
     else hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 128, 3, false, 32>), g, b, 0, stream, p);
@@ -841,9 +898,36 @@ __global__ __launch_bounds__(256, (R * (TN + TC) * 128 > 80 * 1024) ? 1 : 2) voi
     const int ins = wave + 4 * q;
     vqo[q] = (unsigned)((((ins & 3) * 16 + (lane >> 2)) * a.C1 + qcol[q]) * 2);
   }
+  // gathered Q (GatherGeom): a 32-column panel lies inside one tap (ga.C % 32 == 0), so tap and channel offset of each DMA
+  // instruction are wave-uniform; every instruction of a wave covers the same 16 rows of the stage (ins & 3 == wave)
+  const bool gathered = a.ga.on != 0;
+  int qtap[QI];
+  if (gathered) {
+#pragma unroll
+    for (int q = 0; q < QI; ++q) {
+      const int cp = min(c0 + q * 32, a.C - 32);
+      const int t = cp / a.ga.C;
+      qtap[q] = a.ga.tapoff[t];
+      qcol[q] = cp - t * a.ga.C + (lane & 3) * 8;
+    }
+  }
   const bool groupable = a.C2 == 0;
   auto issue = [&](int mb, int st) {
     unsigned char* dst = smem + st * STAGE;
+    if (gathered) {
+      const int mrow = mb + wave * 16 + (lane >> 2);
+      if (mb + BKM <= m_end) {
+        dma16_groupN<PI, 4096>(a.p + (size_t)mb * a.ldp, vpo, dst + wave * 1024);
+      } else {
+#pragma unroll
+        for (int q = 0; q < PI; ++q) dma16(mrow < m_end ? a.p + (size_t)mrow * a.ldp + pcol[q] : zero, dst + (wave + 4 * q) * 1024);
+      }
+      const size_t rb = (size_t)gather_base(a.ga, min(mrow, a.M - 1));
+#pragma unroll
+      for (int q = 0; q < QI; ++q)
+        dma16(a.q1 + (rb + qtap[q]) * a.ga.C + qcol[q], dst + NP * PANEL + (wave + 4 * q) * 1024);
+      return;
+    }
     if (groupable && mb + BKM <= m_end) {
       dma16_groupN<PI, 4096>(a.p + (size_t)mb * a.ldp, vpo, dst + wave * 1024);
       dma16_groupN<QI, 4096>(a.q1 + (size_t)mb * a.C1, vqo, dst + NP * PANEL + wave * 1024);
@@ -920,7 +1004,11 @@ __global__ __launch_bounds__(256, (R * (TN + TC) * 128 > 80 * 1024) ? 1 : 2) voi
       for (int j = 0; j < AJ; ++j) {
         const int c = c0 + (wc * AJ + j) * 32 + r;
         if (c < a.C) {
-          const size_t o = (size_t)n * a.C + c;
+          size_t o = (size_t)n * a.C + c;
+          if (gathered) {   // dw = [taps][N][ga.C]
+            const int t = (c0 + (wc * AJ + j) * 32) / a.ga.C;
+            o = ((size_t)t * a.N + n) * a.ga.C + (c - t * a.ga.C);
+          }
           // (a plain `dw[o] += v` for a sole writer is a dependent load-add-store per element: 64 serialized global
           // round trips per lane, 25 us of a 35 us trunk launch; the no-return atomic is fire-and-forget)
           if (a.part) a.part[(size_t)split * a.N * a.C + o] = acc[i][j][e];

@@ -313,12 +313,17 @@ template <> struct NtDma<bf16> {
     const int K = g->C1 + g->C2;
     // 64-deep stages; K % 64 == 32 runs the 32-deep variant (single source, row-major W only)
     const bool k32 = K % 64 == 32 && g->C2 == 0 && !ep->w_kn;
-    if (!geom_is_plain(g) || (K % 64 != 0 && !k32) || (g->C2 > 0 && g->C1 % 64 != 0) || ctu_option_generic_gemm())
-      return false;
+    if ((K % 64 != 0 && !k32) || (g->C2 > 0 && g->C1 % 64 != 0) || ctu_option_generic_gemm()) return false;
     GemmNtArgs q;
+    q.ga.on = 0;
+    // taps that never leave the grid (patch convolutions, transposed-convolution gradients, strided 1x1x1 shortcuts):
+    // the same kernel with a gathered A operand, K = taps * C
+    if (!geom_is_plain(g) && (ep->w_kn || (ctu_option_route() & CTU_ROUTE_NO_GATHER_GEMM) || !gather_geom_from(g, q.ga)))
+      return false;
     q.a1 = reinterpret_cast<const bf16*>(a1); q.a2 = reinterpret_cast<const bf16*>(a2);
     q.w = reinterpret_cast<const bf16*>(w); q.out = out; q.ep = *ep;
     q.M = p.M; q.N = g->N; q.K = K; q.C1 = g->C1; q.C2 = g->C2;
+    if (q.ga.on) { q.K = q.ga.taps * K; q.C1 = q.K; q.a2 = nullptr; }
     q.w_kn = ep->w_kn;
     if (q.w_kn && (g->C2 > 0 || ep->scatter)) return false;
     if (ep->pre_out && (ep->scatter || ep->n_split > 0 || (ep->splitk > 1 && ep->splitk_ws))) return false;
@@ -686,11 +691,15 @@ template <typename T> struct TnDma {
 };
 template <> struct TnDma<bf16> {
   static bool launch(const TnArgs& a, float* ws, int64_t ws_floats, hipStream_t stream) {
-    if (!geom_is_plain(&a.g) || ctu_option_generic_gemm()) return false;
+    if (ctu_option_generic_gemm()) return false;
     GemmTnArgs q;
+    q.ga.on = 0;
+    if (!geom_is_plain(&a.g) && (a.bias_grad || (ctu_option_route() & CTU_ROUTE_NO_GATHER_GEMM) || !gather_geom_from(&a.g, q.ga)))
+      return false;
     q.p = reinterpret_cast<const bf16*>(a.p); q.q1 = reinterpret_cast<const bf16*>(a.q1);
     q.q2 = reinterpret_cast<const bf16*>(a.q2); q.dw = a.dw; q.bias_grad = a.bias_grad;
     q.ldp = a.ldp; q.M = a.M; q.N = a.g.N; q.C = a.C; q.C1 = a.g.C1; q.C2 = a.g.C2;
+    if (q.ga.on) { q.C = q.ga.taps * q.ga.C; q.C1 = q.C; q.C2 = 0; q.q2 = nullptr; }
     if (launch_gemm_tn_dma(q, ws, ws_floats, stream) != 0) return false;
     if (q.part) {
       const int64_t E = (int64_t)q.N * q.C;

@@ -1630,20 +1630,8 @@ extern "C" int ctu_pwa_bwd(ctu_dtype dtype, const void* qkv1, const void* qkv2, 
 // One thread writes a whole row of P (kpad / 8 vectors): the row's output coordinate is decomposed once, the taps advance by
 // increment with carry, the image reads (L2-resident) of neighbouring rows overlap.  (One thread per 16-byte vector paid nine
 // integer divisions for eight 2-byte reads: 164 us for the 340 MB of the stem's patch matrix, 3x its store time.)
-// division of a value below 2^31 by a launch constant: q = (n * ceil(2^(32 + s) / d)) >> (32 + s), s = ceil(log2 d) (exact for
-// n < 2^31; four instructions instead of the ~40 of a 32-bit division - the kernel spent more on its three divisions per 16-byte
-// store than on the store: 144 us per launch for 113 / 340 MB)
-struct FastDiv { unsigned long long m; int s; int d; };
-static FastDiv fast_div(int d) {
-  FastDiv f;
-  f.d = d;
-  f.s = 0;
-  while ((1ll << f.s) < d) ++f.s;
-  f.m = (((unsigned long long)1 << (32 + f.s)) + (unsigned long long)d - 1) / (unsigned long long)d;
-  return f;
-}
-__device__ __forceinline__ int fdiv(unsigned n, const FastDiv& f) { return (int)(((unsigned long long)n * f.m) >> (32 + f.s)); }
-
+// (The row index is decomposed with FastDiv, common.h: the kernel spent more on its three 32-bit divisions per 16-byte store
+// than on the store - 144 us per launch for 113 / 340 MB.)
 __global__ __launch_bounds__(256) void im2col_cin1_kernel(const bf16* __restrict__ x, bf16* __restrict__ P, const ctu_geom g,
                                                           const int taps, const int kpad, const int64_t M, const FastDiv dkg,
                                                           const FastDiv dwo, const FastDiv dho, const FastDiv ddo) {

@@ -1059,3 +1059,51 @@ def test_narrow_output_gemm(ops, M, K, N, variant):
         assert torch.allclose(got, s_ref, rtol=2e-3, atol=2e-3 * float(s_ref.abs().max())), (got[:4], s_ref[:4])
         assert torch.allclose(accs[0], accs[1], rtol=1e-5, atol=1e-6 * float(accs[1].abs().max()))
         del o
+
+
+@pytest.mark.parametrize("B,din,k,s,C,N", [
+    (2, (12, 12, 24), (2, 2, 2), (2, 2, 2), 128, 256),     # a patch convolution of the ViT branch (hybrid_CTUNet.py:66-83)
+    (1, (8, 12, 20), (2, 2, 1), (2, 2, 1), 64, 128),       # data / weight gradient shape of ConvTranspose3d (2,2,1) (:286-294)
+    (2, (6, 10, 14), (1, 1, 1), (2, 2, 2), 192, 96),       # 1x1x1 stride-2 shortcut (resnet.py:197)
+    (1, (7, 9, 11), (2, 2, 2), (2, 2, 2), 64, 40),         # grid not covered by the taps; N tail
+    (3, (16, 16, 16), (2, 2, 2), (2, 2, 2), 256, 512),     # several m tiles per workgroup column
+])
+def test_gathered_gemm_in_grid_taps(ops, B, din, k, s, C, N):
+    """Convolutions whose taps never leave the grid (no padding) run on the LDS-DMA GEMM kernels with a gathered operand
+    (GatherGeom, gemm_dma.h): forward / data-gradient form (ctu_igemm_nt) and weight-gradient form (ctu_igemm_tn) against
+    float64, and against the generic implicit-GEMM kernels (ctu_set_option("route", 131072))."""
+    from hybrid_ctunet_amd import _lib
+    dt = torch.bfloat16
+    dout = tuple((n - kk) // ss + 1 for n, kk, ss in zip(din, k, s))
+    taps = k[0] * k[1] * k[2]
+    M = B * dout[0] * dout[1] * dout[2]
+    x, xh = dev(rnd((B, *din, C), 5), dt)
+    w, wh = dev(rnd((taps, N, C), 6, 1 / math.sqrt(taps * C)), dt)
+    gy, gyh = dev(rnd((M, N), 7), dt)
+    # gathered rows [M][taps][C] in float64
+    cols = []
+    for td in range(k[0]):
+        for th in range(k[1]):
+            for tw in range(k[2]):
+                cols.append(xh[:, td:td + (dout[0] - 1) * s[0] + 1:s[0], th:th + (dout[1] - 1) * s[1] + 1:s[1],
+                               tw:tw + (dout[2] - 1) * s[2] + 1:s[2], :].reshape(M, C))
+    G = torch.stack(cols, 1)
+    out_ref = torch.einsum("mtc,tnc->mn", G, wh)
+    dw_ref = torch.einsum("mn,mtc->tnc", gyh, G)
+    g = ops._geom(B, din, dout, C, 0, N, k, s, (0, 0, 0), 0)
+    res = []
+    for route in (0, 131072):
+        _lib.call("ctu_set_option", b"route", route)
+        try:
+            out = torch.empty(M, N, device="cuda", dtype=dt)
+            ops._igemm_nt(x, None, w, out, g, ops._epi(N))
+            dw = torch.zeros(taps, N, C, device="cuda")
+            ops._igemm_tn(gy, N, x, None, dw, g)
+            torch.cuda.synchronize()
+            res.append((out, dw))
+        finally:
+            _lib.call("ctu_set_option", b"route", 0)
+    close(res[0][0], out_ref, dt, "out")
+    close(res[0][1], dw_ref, torch.float32, "dw", scale=float(dw_ref.abs().max()) * 4)
+    close(res[1][0], out_ref, dt, "out (generic)")
+    close(res[0][0], res[1][0].double().cpu(), dt, "out: DMA against generic")
