@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libctunet_hip.so")
-SOURCES = ["igemm.hip", "gemm_dma.hip", "gemm_narrow.hip", "conv3_halo.hip", "norm_elementwise.hip", "ff_fused.hip", "attention.hip", "attention_mfma.hip",
+SOURCES = ["igemm.hip", "gemm_dma.hip", "gemm_narrow.hip", "conv3_halo.hip", "norm_elementwise.hip", "ff_fused.hip", "pwa_fused.hip", "attention.hip", "attention_mfma.hip",
            "loss_optim.hip", "infer.hip", "dropout.hip", "comm.hip", "plan.hip", "plan_dispatch.inc", "philox.h", "mma.h", "dma.h", "gemm_dma.h", "attn_common.h", "common.h"]
 
 CTU_F32, CTU_BF16 = 0, 1
@@ -79,6 +79,8 @@ _SIGS = {
     "ctu_attn_dropout_mask": [_vp, _i32, _i32, _f32, C.c_uint64, C.c_uint64, _vp],
     "ctu_ff_pack_w2": [_vp, _vp, _i32, _i32, _vp],
     "ctu_ff_fwd": [_i32] + [_vp] * 11 + [_i64, _i32, _i32, _vp],
+    "ctu_pwa_pack": [_vp, _vp, _vp, _vp, _i32, _vp],
+    "ctu_pwa_block_fwd": [_i32] + [_vp] * 12 + [_i64, _i32, _f32, _vp],
     "ctu_pwa_fwd": [_i32, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "ctu_pwa_bwd": [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "ctu_patchify": [_i32, _vp, _vp] + [_i32] * 7 + [_vp],
@@ -148,7 +150,7 @@ def lib():
         L.ctu_allreduce_scratch_bytes.restype = _i64
         L.ctu_last_error.restype = C.c_char_p
         L.ctu_sync_timeouts.restype = C.c_int
-        if L.ctu_abi_version() != 7:
+        if L.ctu_abi_version() != 8:
             raise RuntimeError("libctunet_hip.so ABI version mismatch")
         _lib = L
     return _lib

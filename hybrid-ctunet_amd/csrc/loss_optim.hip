@@ -24,7 +24,7 @@ int ctu_check_launch(const char* what) {
   return CTU_OK;
 }
 extern "C" const char* ctu_last_error(void) { return g_err; }
-extern "C" int ctu_abi_version(void) { return 7; }
+extern "C" int ctu_abi_version(void) { return 8; }
 
 // ---------------------------------------------------------------------------------------------------------
 // DiceCE

@@ -17,6 +17,7 @@ fused path per (device, stream), so the two paths can be mixed freely within a s
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -44,6 +45,10 @@ OPT = {"gelu2": 1,    # GELU backward inside the data-gradient GEMM of the Linea
                       # whole-model bf16 test holds at twice the reference's own bf16 error (profiles/r04_bench_ab_dual_norm.log)
        "ff1": 1,      # FeedForward forward of the 128-wide stages as ONE kernel (ctu_ff_fwd: LayerNorm, both products and GELU fused;
                       # the backward pass re-derives LayerNorm(x) - the operand of W1's weight gradient - with one LayerNorm launch)
+       "pwa1": 1,     # pixelweight_attention.forward of the 128-wide stages WITHOUT autograd (inference) as ONE kernel (ctu_pwa_block_fwd,
+                      # nothing saved): 204 - 215 us against 488 - 520 for the six launches per 442 368-row call.  Training keeps the six
+                      # launches: with the projections saved the kernel is write-bound at 425 - 460 us and the backward pass would have
+                      # to re-derive both LayerNorms (2 x 45 us) - no gain (profiles/r04_pwa_block_fwd.txt)
        "in1": 0}      # InstanceNorm backward of tensors up to IN_FUSED_BYTES as ONE launch (ctu_in_bwd_fused: reduce, meet at a counter, apply).
                       # Built, parity-tested and measured SLOWER: 21 - 57 us against 13 - 43 for the pair in kbench, 47.4 - 47.8 against
                       # 45.8 - 45.9 ms per step (profiles/r04_experiment_in_bwd_one_launch.log) - two launches of one stream pipeline, a
@@ -1454,6 +1459,36 @@ def pwa_block_ok(m, x1, x2) -> bool:
             and _all_trainable(m))
 
 
+_PWA_PACKED: Dict[int, tuple] = {}
+
+
+def _pwa_packed(m):
+    """The three weight matrices of a pixelweight_attention in the fragment order ctu_pwa_block_fwd streams (ctu_pwa_pack), rebuilt
+    when any of them changes; cached per module (weakly)."""
+    ws = (m.to_qkv1.weight, m.to_qkv2.weight, m.to_out[0].weight)
+    ver = tuple((w._version, w.data_ptr()) for w in ws) + (ops._weights_epoch,)
+    ent = _PWA_PACKED.get(id(m))
+    if ent is not None and ent[0]() is m and ent[1] == ver:
+        ent[3].fence()
+        return ent[2]
+    with torch.no_grad():
+        mir = [ops._linear_weight(w, w, torch.bfloat16) for w in ws]
+        t = torch.empty(4 * 56 * 512, dtype=torch.bfloat16, device=ws[0].device)
+        L.call("ctu_pwa_pack", mir[0].data_ptr(), mir[1].data_ptr(), mir[2].data_ptr(), t.data_ptr(), 128, L.stream())
+    mid = id(m)
+    _PWA_PACKED[mid] = (weakref.ref(m, lambda _r, mid=mid: _PWA_PACKED.pop(mid, None)), ver, t, ops._Built(t.device))
+    return t
+
+
 def pwa_block(m, x1, x2):
+    C = x1.shape[-1]
+    M = x1.numel() // C
+    if OPT["pwa1"] and C == 128 and M % 256 == 0 and not torch.is_grad_enabled():
+        out = torch.empty_like(x1)
+        mr = torch.empty((2, M, 2), dtype=torch.float32, device=x1.device)
+        L.call("ctu_pwa_block_fwd", BF16, x1.data_ptr(), x2.data_ptr(), m.norm1.weight.data_ptr(), m.norm1.bias.data_ptr(),
+               m.norm2.weight.data_ptr(), m.norm2.bias.data_ptr(), _pwa_packed(m).data_ptr(), out.data_ptr(), None, None,
+               mr[0].data_ptr(), mr[1].data_ptr(), M, C, float(m.scale), L.stream())
+        return out
     return PwaBlockFn.apply(x1, x2, m.scale, m.norm1.weight, m.norm1.bias, m.norm2.weight, m.norm2.bias, m.to_qkv1.weight,
                             m.to_qkv2.weight, m.to_out[0].weight)

@@ -325,6 +325,18 @@ int ctu_ff_fwd(ctu_dtype dtype, const void* x, const float* gamma, const float* 
                const void* w2_frag, const float* b2, void* y, void* pre, void* u, float* mean_rstd, int64_t M, int32_t D,
                int32_t Hd, ctu_stream_t stream);
 
+/* pixelweight_attention.forward for C == 128 in one kernel (hybrid_CTUNet.py:645-669: norm1 / norm2, to_qkv1 / to_qkv2, the
+ * cross-weight core below, to_out[0]): out = Wo . mix(Wq1 LN1(x1), Wq2 LN2(x2)).  x1, x2, out: [M][128] bf16.
+ * ctu_pwa_pack: wq1, wq2 = to_qkv1/2.weight [384][128] bf16 row-major (rows q | k | v), wo = to_out[0].weight [128][128] bf16
+ * -> packed, 4 * 56 * 512 bf16 (224 KiB): the MFMA fragments of the three matrices in the order the kernel streams them, per
+ * head (once per optimizer step).
+ * ctu_pwa_block_fwd: qkv1, qkv2: [M][384] bf16 - the projections the backward pass reads (both or neither; NULL: inference,
+ * nothing saved); mean_rstd1/2: fp32 [M][2] as ctu_layernorm_fwd writes them.  M % 256 == 0. */
+int ctu_pwa_pack(const void* wq1, const void* wq2, const void* wo, void* packed, int32_t C, ctu_stream_t stream);
+int ctu_pwa_block_fwd(ctu_dtype dtype, const void* x1, const void* x2, const float* g1, const float* b1, const float* g2,
+                      const float* b2, const void* w_packed, void* out, void* qkv1, void* qkv2, float* mean_rstd1,
+                      float* mean_rstd2, int64_t M, int32_t C, float scale, ctu_stream_t stream);
+
 /* K11 binary cross-weight fusion core (hybrid_CTUNet.py:651-665): per token, per head of 32 channels:
  * a1 = sigmoid(scale*(<q2,k1> - <q1,k2>)); out = a1*v1 + (1-a1)*v2.  qkv1,qkv2: [rows][3*C]; out: [rows][C]. */
 int ctu_pwa_fwd(ctu_dtype dtype, const void* qkv1, const void* qkv2, void* out, int64_t rows, int32_t C,

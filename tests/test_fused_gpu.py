@@ -220,6 +220,32 @@ def test_cross_weight_block_fused_equals_per_op(dim, vol, direct):
     assert any(k[0] == "pwa" for k in F._cache)
 
 
+def test_cross_weight_block_without_autograd_is_one_kernel():
+    """Inference (torch.no_grad) runs pixelweight_attention.forward of a 128-wide stage as ctu_pwa_block_fwd; the result is the
+    launch-list path's (OPT["pwa1"] = 0) up to bf16 rounding of a different summation order, and the packed weight panel follows
+    an in-place weight update."""
+    from hybrid_ctunet_amd.networks import hybrid_CTUNet as N
+    from hybrid_ctunet_amd import ops_fused as F
+    torch.manual_seed(0)
+    m = N.pixelweight_attention(128).cuda()
+    x1, x2 = (torch.randn(2, 12, 12, 24, 128, device="cuda").to(torch.bfloat16) for _ in range(2))   # 6 912 rows
+    outs = []
+    for rep in range(2):
+        with torch.no_grad():
+            for flag in (1, 0):
+                F.OPT["pwa1"] = flag
+                try:
+                    outs.append(m(x1, x2))
+                finally:
+                    F.OPT["pwa1"] = 1
+            torch.cuda.synchronize()
+        _close(outs[-2], outs[-1], "cross-weight forward, one kernel against six", same=0.5)
+        assert id(m) in F._PWA_PACKED
+        with torch.no_grad():
+            m.to_qkv2.weight.mul_(1.5)       # the second round must see the new weights
+    assert not torch.equal(outs[0], outs[2])
+
+
 def test_vit_trunk_with_inner_width_other_than_dim_takes_the_per_op_path():
     """num_heads is a reference CLI flag (main_CTUNet.py:59): 256 wide with 2 heads of 64 has an inner width of 128.  The fused
     trunk sizes its buffers from `dim`, so it must decline, and the shape-generic per-op path must give gradients of the

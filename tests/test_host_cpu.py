@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in ctunet_hip.h but not exported"
     assert sorted(_lib.EXPORTED) == declared, "python binding table and header disagree"
     lib.ctu_abi_version.restype = ctypes.c_int
-    assert lib.ctu_abi_version() == 7
+    assert lib.ctu_abi_version() == 8
 
 
 def test_plan_dispatch_table_is_current_and_packs_every_prototype():

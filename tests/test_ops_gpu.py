@@ -1107,3 +1107,69 @@ def test_gathered_gemm_in_grid_taps(ops, B, din, k, s, C, N):
     close(res[0][1], dw_ref, torch.float32, "dw", scale=float(dw_ref.abs().max()) * 4)
     close(res[1][0], out_ref, dt, "out (generic)")
     close(res[0][0], res[1][0].double().cpu(), dt, "out: DMA against generic")
+
+
+@pytest.mark.parametrize("M,save", [(512, True), (2304, True), (768, False)])
+def test_fused_cross_weight_forward(ops, M, save):
+    """ctu_pwa_block_fwd (pixelweight_attention.forward in one kernel, hybrid_CTUNet.py:645-669) against float64 math on the values
+    the device holds: the output, the saved projections and both LayerNorm statistics; and against the six-launch path."""
+    from hybrid_ctunet_amd._lib import call, dcode, ptr, stream
+    C = 128
+    dt = torch.bfloat16
+    scale = 32 ** -0.5
+    x1, x1h = dev(rnd((M, C), 81, 2.0) + 0.3, dt)
+    x2, x2h = dev(rnd((M, C), 82, 1.5) - 0.2, dt)
+    par = {}
+    for i, n in enumerate(("g1", "g2")):
+        par[n] = dev(1 + 0.2 * rnd((C,), 83 + i), torch.float32)
+    for i, n in enumerate(("b1", "b2")):
+        par[n] = dev(0.1 * rnd((C,), 85 + i), torch.float32)
+    wq1, wq1h = dev(rnd((3 * C, C), 87, 2 / math.sqrt(C)), dt)
+    wq2, wq2h = dev(rnd((3 * C, C), 88, 2 / math.sqrt(C)), dt)
+    wo, woh = dev(rnd((C, C), 89, 1 / math.sqrt(C)), dt)
+    wpk = torch.empty(4 * 56 * 512, device="cuda", dtype=dt)
+    call("ctu_pwa_pack", ptr(wq1), ptr(wq2), ptr(wo), ptr(wpk), C, stream())
+    out = torch.empty(M, C, device="cuda", dtype=dt)
+    q1 = torch.empty(M, 3 * C, device="cuda", dtype=dt) if save else None
+    q2 = torch.empty(M, 3 * C, device="cuda", dtype=dt) if save else None
+    mr1, mr2 = torch.empty(M, 2, device="cuda"), torch.empty(M, 2, device="cuda")
+    for _ in range(2):   # (second call: the stage ring starts from the state the first left)
+        call("ctu_pwa_block_fwd", dcode(dt), ptr(x1), ptr(x2), ptr(par["g1"][0]), ptr(par["b1"][0]), ptr(par["g2"][0]), ptr(par["b2"][0]),
+             ptr(wpk), ptr(out), ptr(q1), ptr(q2), ptr(mr1), ptr(mr2), M, C, scale, stream())
+    torch.cuda.synchronize()
+
+    def ln(xh, g, b):
+        mean = xh.mean(1, keepdim=True)
+        rstd = 1 / torch.sqrt(xh.var(1, unbiased=False, keepdim=True) + 1e-5)
+        return ((xh - mean) * rstd * g + b).to(dt).double(), mean.squeeze(1), rstd.squeeze(1)   # (rounded: MFMA operand)
+
+    h1, m1, r1 = ln(x1h, par["g1"][1], par["b1"][1])
+    h2, m2, r2 = ln(x2h, par["g2"][1], par["b2"][1])
+    p1 = (h1 @ wq1h.t()).to(dt).double()      # the projections are rounded to bf16 before the mix, as the stored copies are
+    p2 = (h2 @ wq2h.t()).to(dt).double()
+    qa, ka, va = (t.view(M, 4, 32) for t in p1.split(C, 1))
+    qb, kb, vb = (t.view(M, 4, 32) for t in p2.split(C, 1))
+    z = ((qb * ka).sum(-1) - (qa * kb).sum(-1)) * scale
+    a1 = torch.sigmoid(z).unsqueeze(-1)
+    o = (a1 * va + (1 - a1) * vb).reshape(M, C).to(dt).double()
+    out_ref = o @ woh.t()
+    close(mr1[:, 0], m1, torch.float32, "mean1"), close(mr1[:, 1], r1, torch.float32, "rstd1")
+    close(mr2[:, 0], m2, torch.float32, "mean2"), close(mr2[:, 1], r2, torch.float32, "rstd2")
+    if save:
+        close(q1, p1, dt, "qkv1"), close(q2, p2, dt, "qkv2")
+    close(out, out_ref, dt, "out")
+    # the six-launch path on the same inputs
+    hh1, hh2 = torch.empty_like(x1), torch.empty_like(x2)
+    t1, t2 = torch.empty(M, 2, device="cuda"), torch.empty(M, 2, device="cuda")
+    call("ctu_layernorm_fwd", dcode(dt), ptr(x1), ptr(par["g1"][0]), ptr(par["b1"][0]), ptr(hh1), ptr(t1), M, C, stream())
+    call("ctu_layernorm_fwd", dcode(dt), ptr(x2), ptr(par["g2"][0]), ptr(par["b2"][0]), ptr(hh2), ptr(t2), M, C, stream())
+    s1, s2 = torch.empty(M, 3 * C, device="cuda", dtype=dt), torch.empty(M, 3 * C, device="cuda", dtype=dt)
+    ops._plain_gemm(hh1, wq1, s1, M, C, 3 * C)
+    ops._plain_gemm(hh2, wq2, s2, M, C, 3 * C)
+    oo, out6 = torch.empty(M, C, device="cuda", dtype=dt), torch.empty(M, C, device="cuda", dtype=dt)
+    call("ctu_pwa_fwd", dcode(dt), ptr(s1), ptr(s2), ptr(oo), M, C, scale, stream())
+    ops._plain_gemm(oo, wo, out6, M, C, C)
+    torch.cuda.synchronize()
+    close(out, out6.double().cpu(), dt, "out against the six-launch path")
+    if save:
+        assert (q1 == s1).float().mean().item() > 0.99 and (q2 == s2).float().mean().item() > 0.99

@@ -9,7 +9,7 @@ make -j4 >/dev/null
 mkdir -p variants
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function "$@" -c "$src" -o "variants/${src%.hip}_$tag.o"
 objs=""
-for f in igemm gemm_dma gemm_narrow conv3_halo norm_elementwise ff_fused attention attention_mfma loss_optim infer dropout comm plan; do
+for f in igemm gemm_dma gemm_narrow conv3_halo norm_elementwise ff_fused pwa_fused attention attention_mfma loss_optim infer dropout comm plan; do
   if [ "$f.hip" = "$src" ]; then objs="$objs variants/${f}_$tag.o"; else objs="$objs $f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "variants/libctunet_hip_$tag.so" $objs -ldl

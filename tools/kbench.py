@@ -183,6 +183,46 @@ def ff(M, Hd):
     report(f"ff three launches M={M} D={D} Hd={Hd}", timeit(three), 4.0 * M * D * Hd, byt)
 
 
+def pwa(M):
+    """Fused cross-weight forward (ctu_pwa_block_fwd, with and without the saved projections) against the six launches it replaces."""
+    C = 128
+    sets = 3
+    x1 = [torch.randn(M, C, device=dev, dtype=DT) for _ in range(sets)]
+    x2 = [torch.randn(M, C, device=dev, dtype=DT) for _ in range(sets)]
+    g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    wq1, wq2 = torch.randn(3 * C, C, device=dev, dtype=DT) * 0.09, torch.randn(3 * C, C, device=dev, dtype=DT) * 0.09
+    wo = torch.randn(C, C, device=dev, dtype=DT) * 0.09
+    wpk = torch.empty(4 * 56 * 512, device=dev, dtype=DT)
+    call("ctu_pwa_pack", ptr(wq1), ptr(wq2), ptr(wo), ptr(wpk), C, stream())
+    outs = [torch.empty(M, C, device=dev, dtype=DT) for _ in range(sets)]
+    q1 = [torch.empty(M, 3 * C, device=dev, dtype=DT) for _ in range(sets)]
+    q2 = [torch.empty(M, 3 * C, device=dev, dtype=DT) for _ in range(sets)]
+    h1 = [torch.empty(M, C, device=dev, dtype=DT) for _ in range(sets)]
+    h2 = [torch.empty(M, C, device=dev, dtype=DT) for _ in range(sets)]
+    oo = [torch.empty(M, C, device=dev, dtype=DT) for _ in range(sets)]
+    mr1, mr2 = torch.empty(M, 2, device=dev), torch.empty(M, 2, device=dev)
+    it = [0]
+    scale = 32 ** -0.5
+
+    def fused(save):
+        i = it[0] = (it[0] + 1) % sets
+        call("ctu_pwa_block_fwd", dcode(DT), ptr(x1[i]), ptr(x2[i]), ptr(g), ptr(b), ptr(g), ptr(b), ptr(wpk), ptr(outs[i]),
+             ptr(q1[i]) if save else None, ptr(q2[i]) if save else None, ptr(mr1), ptr(mr2), M, C, scale, stream())
+
+    def six():
+        i = it[0] = (it[0] + 1) % sets
+        call("ctu_layernorm_fwd", dcode(DT), ptr(x1[i]), ptr(g), ptr(b), ptr(h1[i]), ptr(mr1), M, C, stream())
+        ops._plain_gemm(h1[i], wq1, q1[i], M, C, 3 * C)
+        call("ctu_layernorm_fwd", dcode(DT), ptr(x2[i]), ptr(g), ptr(b), ptr(h2[i]), ptr(mr2), M, C, stream())
+        ops._plain_gemm(h2[i], wq2, q2[i], M, C, 3 * C)
+        call("ctu_pwa_fwd", dcode(DT), ptr(q1[i]), ptr(q2[i]), ptr(oo[i]), M, C, scale, stream())
+        ops._plain_gemm(oo[i], wo, outs[i], M, C, C)
+    flop = 2.0 * M * C * (6 * C + C)
+    report(f"pwa fused, projections saved M={M}", timeit(lambda: fused(True)), flop, 2.0 * M * (3 * C + 6 * C))
+    report(f"pwa fused, nothing saved     M={M}", timeit(lambda: fused(False)), flop, 2.0 * M * 3 * C)
+    report(f"pwa six launches             M={M}", timeit(six), flop, 2.0 * M * (3 * C + 6 * C))
+
+
 def colsum(M, N, scaled):
     x = torch.randn(M, N, device=dev, dtype=DT)
     rs = torch.randn(M, device=dev, dtype=DT) if scaled else None
@@ -194,6 +234,7 @@ def colsum(M, N, scaled):
 CASES = {
     "colsum": lambda: [colsum(1769472, 64, True), colsum(1769472, 64, True), colsum(1769472, 16, False), colsum(442368, 128, False)],
     "ff": lambda: [ff(442368, 512), ff(55296, 512)],
+    "pwa": lambda: [pwa(442368), pwa(55296)],
     "tn_trunk": lambda: [tn(864, 3072, 768), tn(864, 768, 3072), tn(864, 2304, 768), tn(864, 768, 768)],
     "tn_big": lambda: [tn(442368, 512, 128), tn(442368, 128, 512), tn(442368, 384, 128), tn(442368, 128, 32),
                        tn(442368, 32, 128), tn(55296, 768, 256), tn(55296, 256, 64), tn(1769472, 16, 64),
