@@ -25,6 +25,14 @@ __device__ __forceinline__ int gather_base(const GatherGeom& g, int m) {
   const int od = m - q * g.dDo.d;
   return q * g.sB + od * g.sD + oh * g.sH + ow * g.sW;
 }
+// tapoff[t] for a wave-uniform t without indexing the kernel argument dynamically (that copies the table to scratch memory
+// and puts a scratch load on every stage issue)
+__device__ __forceinline__ int gather_tapoff(const GatherGeom& g, int t) {
+  int off = g.tapoff[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) off = t == i ? g.tapoff[i] : off;
+  return off;
+}
 // fills `gg` when `g` is such a geometry (mode 0) with C1 % 64 == 0 channels and no second source
 bool gather_geom_from(const ctu_geom* g, GatherGeom& gg);
 

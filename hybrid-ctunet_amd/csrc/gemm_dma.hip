@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 2 || R * (BM + BN) * BK * 2 > 76 *
       unsigned va[APW], vb[BPW];
 #pragma unroll
       for (int j = 0; j < APW; ++j) va[j] = ((unsigned)abase[j] * (unsigned)C + (unsigned)(aslot[j] * 8)) * 2u;
-      dma16_groupN<APW, 1024>(p.a1 + (size_t)p.ga.tapoff[t] * C + kin, va, sa + APW * wave * 1024);
+      dma16_groupN<APW, 1024>(p.a1 + (size_t)gather_tapoff(p.ga, t) * C + kin, va, sa + APW * wave * 1024);
       const int nrem = p.N - 1 - it.n0;
 #pragma unroll
       for (int j = 0; j < BPW; ++j) vb[j] = (unsigned)((min(brow[j], nrem) * C + bslot[j] * 8) * 2);
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256, (R * (TN + TC) * 128 > 80 * 1024) ? 1 : 2) voi
     for (int q = 0; q < QI; ++q) {
       const int cp = min(c0 + q * 32, a.C - 32);
       const int t = cp / a.ga.C;
-      qtap[q] = a.ga.tapoff[t];
+      qtap[q] = gather_tapoff(a.ga, t);
       qcol[q] = cp - t * a.ga.C + (lane & 3) * 8;
     }
   }

@@ -46,9 +46,10 @@ OPT = {"gelu2": 1,    # GELU backward inside the data-gradient GEMM of the Linea
        "ff1": 1,      # FeedForward forward of the 128-wide stages as ONE kernel (ctu_ff_fwd: LayerNorm, both products and GELU fused;
                       # the backward pass re-derives LayerNorm(x) - the operand of W1's weight gradient - with one LayerNorm launch)
        "pwa1": 1,     # pixelweight_attention.forward of the 128-wide stages WITHOUT autograd (inference) as ONE kernel (ctu_pwa_block_fwd,
-                      # nothing saved): 204 - 215 us against 488 - 520 for the six launches per 442 368-row call.  Training keeps the six
-                      # launches: with the projections saved the kernel is write-bound at 425 - 460 us and the backward pass would have
-                      # to re-derive both LayerNorms (2 x 45 us) - no gain (profiles/r04_pwa_block_fwd.txt)
+                      # nothing saved): 191 us against 480 - 520 for the six launches per 442 368-row call.  Training keeps the six
+                      # launches: with the projections saved the kernel takes 395 - 415 us and the backward pass would still have to
+                      # re-derive both LayerNorms (2 x 45 us) - no gain without a backward kernel that recomputes the projections
+                      # (profiles/r04_pwa_block_fwd.txt)
        "in1": 0}      # InstanceNorm backward of tensors up to IN_FUSED_BYTES as ONE launch (ctu_in_bwd_fused: reduce, meet at a counter, apply).
                       # Built, parity-tested and measured SLOWER: 21 - 57 us against 13 - 43 for the pair in kbench, 47.4 - 47.8 against
                       # 45.8 - 45.9 ms per step (profiles/r04_experiment_in_bwd_one_launch.log) - two launches of one stream pipeline, a
@@ -1483,7 +1484,7 @@ def _pwa_packed(m):
 def pwa_block(m, x1, x2):
     C = x1.shape[-1]
     M = x1.numel() // C
-    if OPT["pwa1"] and C == 128 and M % 256 == 0 and not torch.is_grad_enabled():
+    if OPT["pwa1"] and C == 128 and M % 128 == 0 and not torch.is_grad_enabled():
         out = torch.empty_like(x1)
         mr = torch.empty((2, M, 2), dtype=torch.float32, device=x1.device)
         L.call("ctu_pwa_block_fwd", BF16, x1.data_ptr(), x2.data_ptr(), m.norm1.weight.data_ptr(), m.norm1.bias.data_ptr(),

@@ -331,7 +331,7 @@ int ctu_ff_fwd(ctu_dtype dtype, const void* x, const float* gamma, const float* 
  * -> packed, 4 * 56 * 512 bf16 (224 KiB): the MFMA fragments of the three matrices in the order the kernel streams them, per
  * head (once per optimizer step).
  * ctu_pwa_block_fwd: qkv1, qkv2: [M][384] bf16 - the projections the backward pass reads (both or neither; NULL: inference,
- * nothing saved); mean_rstd1/2: fp32 [M][2] as ctu_layernorm_fwd writes them.  M % 256 == 0. */
+ * nothing saved); mean_rstd1/2: fp32 [M][2] as ctu_layernorm_fwd writes them.  M % 128 == 0. */
 int ctu_pwa_pack(const void* wq1, const void* wq2, const void* wo, void* packed, int32_t C, ctu_stream_t stream);
 int ctu_pwa_block_fwd(ctu_dtype dtype, const void* x1, const void* x2, const float* g1, const float* b1, const float* g2,
                       const float* b2, const void* w_packed, void* out, void* qkv1, void* qkv2, float* mean_rstd1,

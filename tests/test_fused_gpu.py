@@ -239,7 +239,8 @@ def test_cross_weight_block_without_autograd_is_one_kernel():
                 finally:
                     F.OPT["pwa1"] = 1
             torch.cuda.synchronize()
-        _close(outs[-2], outs[-1], "cross-weight forward, one kernel against six", same=0.5)
+        # (without saved projections the kernel mixes the fp32 accumulators of q / k / v, the six-launch path their bf16 roundings)
+        _close(outs[-2], outs[-1], "cross-weight forward, one kernel against six", same=0.0)
         assert id(m) in F._PWA_PACKED
         with torch.no_grad():
             m.to_qkv2.weight.mul_(1.5)       # the second round must see the new weights
