@@ -1107,6 +1107,14 @@ def test_gathered_gemm_in_grid_taps(ops, B, din, k, s, C, N):
     close(res[0][1], dw_ref, torch.float32, "dw", scale=float(dw_ref.abs().max()) * 4)
     close(res[1][0], out_ref, dt, "out (generic)")
     close(res[0][0], res[1][0].double().cpu(), dt, "out: DMA against generic")
+    # the epilogues the model puts behind these layers: split K through a workspace (patch convolutions at 864 rows), residual
+    sk = 4 if taps * C >= 1024 else 1
+    ws = torch.zeros(M * N, device="cuda") if sk > 1 else None
+    resid, residh = dev(rnd((M, N), 8), dt)
+    out2 = torch.empty(M, N, device="cuda", dtype=dt)
+    ops._igemm_nt(x, None, w, out2, g, ops._epi(N, residual=resid, splitk_ws=ws, splitk=sk))
+    torch.cuda.synchronize()
+    close(out2, out_ref + residh, dt, f"out + residual, split K {sk}")
 
 
 @pytest.mark.parametrize("M,save", [(512, True), (2304, True), (768, False)])
