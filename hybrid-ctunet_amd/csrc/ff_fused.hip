@@ -70,6 +70,7 @@ __device__ __forceinline__ float gelu_fast(float v) {
   return v < 0.f ? half : v - half;
 }
 
+template <bool SAVE>
 __global__ __launch_bounds__(512, 1) void ff_fwd_kernel(const FfArgs p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* wst = smem;                                  // 2 weight stages
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(512, 1) void ff_fwd_kernel(const FfArgs p) {
       // stage `seq` was issued one chunk ago (or in the prologue); younger than it at this point: the 8 stores of the
       // previous chunk (and, behind a tile's last chunk, the 8 stores of y) - never fewer, so vmcnt(8) covers the stage
       if (seq == 0) wait_vm_then_barrier<0>();
-      else wait_vm_then_barrier<8>();
+      else wait_vm_then_barrier<SAVE ? 8 : 0>();   // (nothing saved - inference: no chunk stores, only the 8 stores of y per tile)
       {
         const int cn = c + 1 < p.nch ? c + 1 : 0;   // (past the last tile: one stage nobody reads - keeps the counts static)
         issue_stage(cn, (seq + 1) & 1);
@@ -194,12 +195,14 @@ __global__ __launch_bounds__(512, 1) void ff_fwd_kernel(const FfArgs p) {
 #endif
             acc[4 * q + j] = uv[j];
           }
-          typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-          bf16x4 pb, ub;
+          if (SAVE) {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            bf16x4 pb, ub;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { pb[j] = (bf16)pv[j]; ub[j] = (bf16)uv[j]; }
-          *reinterpret_cast<bf16x4*>(spre + r * 72 + 32 * t + 4 * hf + 8 * q) = pb;
-          *reinterpret_cast<bf16x4*>(su + r * 72 + 32 * t + 4 * hf + 8 * q) = ub;
+            for (int j = 0; j < 4; ++j) { pb[j] = (bf16)pv[j]; ub[j] = (bf16)uv[j]; }
+            *reinterpret_cast<bf16x4*>(spre + r * 72 + 32 * t + 4 * hf + 8 * q) = pb;
+            *reinterpret_cast<bf16x4*>(su + r * 72 + 32 * t + 4 * hf + 8 * q) = ub;
+          }
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -219,22 +222,24 @@ __global__ __launch_bounds__(512, 1) void ff_fwd_kernel(const FfArgs p) {
             accY[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, ufrag[t][a], accY[n], 0, 0, 0);
           }
       // pre / u of this chunk leave as 128-byte row segments: lane -> (row 8 i + (lane >> 3), 16-byte group lane & 7)
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const int64_t row0 = (int64_t)tile * FF_ROWS + wave * 32;
+      if (SAVE) {
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int64_t row0 = (int64_t)tile * FF_ROWS + wave * 32;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rr = 8 * i + (lane >> 3), cg = lane & 7;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(spre + rr * 72 + cg * 8);
-        store16_asm(p.pre + (size_t)(row0 + rr) * p.Hd + FF_CH * c + cg * 8, v);
-      }
+        for (int i = 0; i < 4; ++i) {
+          const int rr = 8 * i + (lane >> 3), cg = lane & 7;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(spre + rr * 72 + cg * 8);
+          store16_asm(p.pre + (size_t)(row0 + rr) * p.Hd + FF_CH * c + cg * 8, v);
+        }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rr = 8 * i + (lane >> 3), cg = lane & 7;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(su + rr * 72 + cg * 8);
-        store16_asm(p.u + (size_t)(row0 + rr) * p.Hd + FF_CH * c + cg * 8, v);
+        for (int i = 0; i < 4; ++i) {
+          const int rr = 8 * i + (lane >> 3), cg = lane & 7;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(su + rr * 72 + cg * 8);
+          store16_asm(p.u + (size_t)(row0 + rr) * p.Hd + FF_CH * c + cg * 8, v);
+        }
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
     }
     // ---- y = x + (W2 u) + b2: two feature tiles at a time through the staging tile in fp32 (one rounding, as the GEMM epilogue)
     {
@@ -306,7 +311,8 @@ extern "C" int ctu_ff_fwd(ctu_dtype dtype, const void* x, const float* gamma, co
                           const void* w2_frag, const float* b2, void* y, void* pre, void* u, float* mean_rstd, int64_t M,
                           int32_t D, int32_t Hd, ctu_stream_t stream) {
   CTU_REQUIRE(dtype == CTU_BF16, "ff_fwd: bf16 only");
-  CTU_REQUIRE(x && gamma && beta && w1 && b1 && w2_frag && b2 && y && pre && u && mean_rstd, "ff_fwd: null pointer");
+  CTU_REQUIRE(x && gamma && beta && w1 && b1 && w2_frag && b2 && y && mean_rstd, "ff_fwd: null pointer");
+  CTU_REQUIRE((pre == nullptr) == (u == nullptr), "ff_fwd: pre and u are saved together or not at all");
   CTU_REQUIRE(D == FF_D && Hd >= 2 * FF_CH && Hd % FF_CH == 0 && Hd <= 4096, "ff_fwd: D = 128, Hd a multiple of 64 in [128, 4096] (D=%d Hd=%d)", D, Hd);
   CTU_REQUIRE(M > 0 && M % FF_ROWS == 0 && M * (int64_t)Hd < (1ll << 40), "ff_fwd: M must be a multiple of 256 (M=%lld)", (long long)M);
   FfArgs p;
@@ -316,13 +322,15 @@ extern "C" int ctu_ff_fwd(ctu_dtype dtype, const void* x, const float* gamma, co
   const size_t lds = 2 * FF_STAGE + 8 * FF_STG_WAVE + (3 * FF_D + Hd) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ff_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ff_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(ff_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       ctu_set_error("ff_fwd: cannot raise the dynamic LDS limit");
       return CTU_ERR_ARG;
     }
     attr_set = true;
   }
   const int grid = p.ntiles < 256 ? p.ntiles : 256;
-  hipLaunchKernelGGL(ff_fwd_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
+  if (pre) hipLaunchKernelGGL(ff_fwd_kernel<true>, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(ff_fwd_kernel<false>, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
   return ctu_check_launch("ff_fwd");
 }

@@ -75,7 +75,8 @@ def usable(x: torch.Tensor) -> bool:
 
 
 def _flags():
-    return (ops.B16_LAYOUT, ops.WGRAD_PARTIALS, ops.WGRAD_STREAM, tuple(OPT.values()))
+    # (autograd on / off is part of every plan key: a forward recorded without it writes nothing a backward pass would read)
+    return (ops.B16_LAYOUT, ops.WGRAD_PARTIALS, ops.WGRAD_STREAM, tuple(OPT.values()), torch.is_grad_enabled())
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -186,7 +187,7 @@ class _Need:
 def em_gemm(R: Recorder, need: _Need, x, w, out, M, K, N, *, bias=None, residual=None, act=0, w_kn=0, in_acc=None,
             in_rows=0, pre_out=None, stream=0):
     """ops._plain_gemm: out[M,N] = act(x[M,K] @ w^T + bias) + residual."""
-    sk = 1 if (in_acc is not None or pre_out is not None or act == 2) else ops._splitk_for(M, N, K, dma=K % 32 == 0)
+    sk = 1 if (in_acc is not None or pre_out is not None or act != 0) else ops._splitk_for(M, N, K, dma=K % 32 == 0)
     if sk > 1:
         need.skws = max(need.skws, M * N)
     e = _epi(N, bias=bias, residual=residual, act=act, splitk_ws=R["skws"] if sk > 1 else None, splitk=sk, w_kn=w_kn,
@@ -837,6 +838,7 @@ class FFRes(_Layer):
         self.lin = ("w1", "w2")
         # the forward as ONE kernel (ctu_ff_fwd) where its tile shapes fit: width 128, 256-row tiles, 64-unit hidden chunks
         self.fused_fwd = bool(OPT["ff1"] and dim == 128 and hidden % 64 == 0 and 128 <= hidden <= 4096 and M % 256 == 0)
+        self.save = torch.is_grad_enabled()   # (without autograd the fused kernel writes neither `pre` nor `u`: 2.3 GB per 442 k-row call)
         if self.fused_fwd:
             self.packed = (("w2f", "w2"),)
 
@@ -845,6 +847,8 @@ class FFRes(_Layer):
         for nm, nb in (("h", M * D * 2), ("mr", M * 8), ("pre", M * Hd * 2), ("u", M * Hd * 2), ("y", M * D * 2)):
             if nm == "h" and self.fused_fwd:
                 G.add(self.n(nm), nb)     # LayerNorm(x) is never written forward: the backward pass re-derives it
+            elif not self.save and (nm == "pre" or (nm == "u" and self.fused_fwd)):
+                pass                      # read by a backward pass only
             else:
                 F.add(self.n(nm), nb)
         fused_gelu = D % 64 == 0 and Hd % 8 == 0 and OPT["gelu2"]
@@ -854,11 +858,11 @@ class FFRes(_Layer):
     def fwd(self, R, need, x):
         n, M, D, Hd = self.n, self.M, self.dim, self.hidden
         if self.fused_fwd:
-            R.call("ctu_ff_fwd", BF16, x, R[n("g")], R[n("b")], R[n("w1")], R[n("b1")], R[n("w2f")], R[n("b2")], R[n("y")], R[n("pre")],
-                   R[n("u")], R[n("mr")], M, D, Hd)
+            R.call("ctu_ff_fwd", BF16, x, R[n("g")], R[n("b")], R[n("w1")], R[n("b1")], R[n("w2f")], R[n("b2")], R[n("y")],
+                   R[n("pre")] if self.save else None, R[n("u")] if self.save else None, R[n("mr")], M, D, Hd)
             return R[n("y")]
         R.call("ctu_layernorm_fwd", BF16, x, R[n("g")], R[n("b")], R[n("h")], R[n("mr")], M, D)
-        em_gemm(R, need, R[n("h")], R[n("w1")], R[n("u")], M, D, Hd, bias=R[n("b1")], act=1, pre_out=R[n("pre")])
+        em_gemm(R, need, R[n("h")], R[n("w1")], R[n("u")], M, D, Hd, bias=R[n("b1")], act=1, pre_out=R[n("pre")] if self.save else None)
         em_gemm(R, need, R[n("u")], R[n("w2")], R[n("y")], M, Hd, D, bias=R[n("b2")], residual=x)
         return R[n("y")]
 

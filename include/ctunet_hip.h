@@ -318,8 +318,8 @@ int ctu_attn_bwd(ctu_dtype dtype, const void* qkv, const float* bias_table, cons
  * y = x + W2 gelu(W1 LayerNorm(x) + b1) + b2 in one kernel; the normalised rows and the hidden activations stay in registers
  * between the two products.  x, y: [M][128] bf16; w1: [Hd][128] bf16 row-major; w2_frag: W2 ([128][Hd] bf16) re-ordered by
  * ctu_ff_pack_w2 (once per optimizer step); pre, u: [M][Hd] bf16 - the pre-activation and gelu(pre) the backward pass reads
- * (GELU', operand of W2's weight gradient); mean_rstd: fp32 [M][2] as ctu_layernorm_fwd writes it.  M % 256 == 0,
- * D == 128, Hd % 64 == 0. */
+ * (GELU', operand of W2's weight gradient), both NULL for inference (nothing but y and the statistics is written); mean_rstd:
+ * fp32 [M][2] as ctu_layernorm_fwd writes it.  M % 256 == 0, D == 128, Hd % 64 == 0. */
 int ctu_ff_pack_w2(const void* w2, void* w2_frag, int32_t D, int32_t Hd, ctu_stream_t stream);
 int ctu_ff_fwd(ctu_dtype dtype, const void* x, const float* gamma, const float* beta, const void* w1, const float* b1,
                const void* w2_frag, const float* b2, void* y, void* pre, void* u, float* mean_rstd, int64_t M, int32_t D,

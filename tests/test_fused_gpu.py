@@ -220,6 +220,31 @@ def test_cross_weight_block_fused_equals_per_op(dim, vol, direct):
     assert any(k[0] == "pwa" for k in F._cache)
 
 
+def test_up_attention_stage_without_autograd_saves_nothing_and_agrees():
+    """Under torch.no_grad() a stage's plan is recorded without the tensors only a backward pass reads (ctu_ff_fwd with pre = u =
+    NULL): the output is bit-equal to the forward with autograd on - the arithmetic is the same, only stores are left out."""
+    from hybrid_ctunet_amd.networks import hybrid_CTUNet as N
+    from hybrid_ctunet_amd import ops_fused as F
+    torch.manual_seed(0)
+    up = N.UpAttentionBlock(3, 128, dims=[32, 64, 128, 256]).cuda()
+    blk = up.layers[1][0]
+    x = torch.randn(2, 12, 12, 24, 128, device="cuda").to(torch.bfloat16)
+    assert F.up_stage_ok(x, blk, 1, False)
+    y_grad = N.UpAttentionBlock._run_stage(blk, 1, x.clone().requires_grad_(True))
+    with torch.no_grad():
+        y_nograd = N.UpAttentionBlock._run_stage(blk, 1, x)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        off = F._flags()
+    on = F._flags()
+    mine = {k[-1]: pl for k, pl in F._cache.items() if k[0] == "upstage" and k[2:7] == (2, 12, 12, 24, 128)}
+    assert on in mine and off in mine and on != off          # two plans: with and without autograd
+    assert torch.equal(y_grad.detach(), y_nograd)
+    ff = [l for l in mine[off].layers if isinstance(l, F.FFRes)]
+    assert ff and all(l.fused_fwd and not l.save for l in ff)
+    assert all(l.save for l in mine[on].layers if isinstance(l, F.FFRes))
+
+
 def test_cross_weight_block_without_autograd_is_one_kernel():
     """Inference (torch.no_grad) runs pixelweight_attention.forward of a 128-wide stage as ctu_pwa_block_fwd; the result is the
     launch-list path's (OPT["pwa1"] = 0) up to bf16 rounding of a different summation order, and the packed weight panel follows
