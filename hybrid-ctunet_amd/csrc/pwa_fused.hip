@@ -26,10 +26,17 @@
 // The fragments are read from LDS by a hand-placed stream (ds_read_b128 in assembly, four steps = eight fragments ahead of
 // the MFMAs that use them, counted lgkmcnt): every MFMA here needs one 1-KiB fragment, and the compiler's order (read, wait,
 // MFMA) exposes the LDS latency at every step - with one wave per SIMD nothing else would cover it.
+#include <atomic>
+
 #include "dma.h"
 #include "mma.h"
 
 namespace {
+
+// Tile dispensers: a launch takes the next of 64 slots (two launches on two streams never share one; a slot comes round again
+// 64 launches later, long after its last workgroup zeroed it).
+__device__ unsigned g_pwa_ticket[64];
+__device__ unsigned g_pwa_done[64];
 
 constexpr int PW_C = 128;
 constexpr int PW_ROWS = 128;          // rows per workgroup tile (4 waves x 32)
@@ -53,6 +60,8 @@ struct PwaArgs {
   int64_t M;
   int ntiles;
   float scale;
+  unsigned* ticket;  // tile dispenser of this launch: tiles beyond the first (blockIdx.x) are taken with atomicAdd (see the kernel)
+  unsigned* done;    // workgroups that are through: the last one hands both counters back zeroed
 };
 
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
@@ -235,13 +244,22 @@ __global__ __launch_bounds__(256, 1) void pwa_block_fwd_kernel(const PwaArgs p) 
     }
   };
 
+  // Tiles are DISPENSED, not dealt: the first is blockIdx.x, every further one the next ticket.  The kernel wants a whole CU per
+  // workgroup (146 KiB of LDS), and beside another stream's kernel part of the 256 workgroups start late - dealt tiles then made
+  // the launch wait for the latecomers' whole share (inference: 360 us alone, 630 us beside the other branch).  Wave 0 draws the
+  // ticket for the tile after next in head 2 (behind that head's DMA), parks it in LDS behind head 3's wait - which covers the
+  // atomic's return on the in-order counter anyway - and every wave reads it behind the next tile's first barrier.
+  unsigned* tick = reinterpret_cast<unsigned*>(cst + 4 * PW_C);   // [0]: the tile after the current one
   int seq = 0;
   [[maybe_unused]] int nst = 0;
   issue_stage(0, 0);
   if ((int)blockIdx.x < p.ntiles) request_rows(blockIdx.x);
-  __syncthreads();   // constants in LDS (and, this once, the first stage and rows: everything has landed)
+  if (tid == 0) tick[0] = (unsigned)gridDim.x + atomicAdd(p.ticket, 1u);
+  __syncthreads();   // constants in LDS (and, this once, the first stage, rows and ticket: everything has landed)
   int prev_tile = -1;
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+  int next_tile = (int)tick[0];
+  unsigned drawn = 0;
+  for (int tile = blockIdx.x; tile < p.ntiles; tile = next_tile) {
     const unsigned row = (unsigned)(tile * PW_ROWS + wave * 32 + r);
     const unsigned qoff = row * (3 * PW_C * 2) + 8 * hf;   // byte offset of this lane's first 4 channels in a [M][384] row
     PW_STAMP();
@@ -266,12 +284,17 @@ __global__ __launch_bounds__(256, 1) void pwa_block_fwd_kernel(const PwaArgs p) 
       else if (hd == 0) wait_vm_then_barrier<YOUNGER + 2>();    // behind the DMA of this stage: the two stores of the LayerNorm statistics
       else if (hd == 1) wait_vm_then_barrier<YOUNGER + 24>();   // behind the DMA of this stage: 8 row stores + 16 row loads (below)
       else wait_vm_then_barrier<YOUNGER>();
+      if (hd == 3 && tid == 0) tick[0] = drawn;   // (here, in front of the DMA: the wait above has already covered the atomic's return;
+                                                  // every wave reads it behind the next tile's first barrier)
       issue_stage((hd + 1) & 3, (seq + 1) & 1);   // (past the last tile: one stage nobody reads - keeps the counts static)
       if (hd == 0) {
         // the previous tile's rows (first tile: this tile's staging area as it is - rewritten below by the real rows) and the
         // next tile's rows (past the last tile: the same rows again): behind this head's DMA, ahead of everything that waits
+        if (prev_tile >= 0) next_tile = (int)tick[0];   // (drawn in the previous tile's head 2, parked behind its head 3 wait)
         store_rows(prev_tile >= 0 ? prev_tile : tile);
-        request_rows(tile + (int)gridDim.x < p.ntiles ? tile + (int)gridDim.x : tile);
+        request_rows(next_tile < p.ntiles ? next_tile : tile);
+      } else if (hd == 2) {
+        if (tid == 0) drawn = (unsigned)gridDim.x + atomicAdd(p.ticket, 1u);
       }
       const unsigned wba = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(wst + (seq & 1) * PW_STAGE + lane * 16);
       PW_STAMP();
@@ -358,6 +381,10 @@ __global__ __launch_bounds__(256, 1) void pwa_block_fwd_kernel(const PwaArgs p) 
   }
   if (prev_tile >= 0) store_rows(prev_tile);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stage nobody reads has landed before the workgroup's LDS is released
+  if (tid == 0 && atomicAdd(p.done, 1u) == gridDim.x - 1) {   // the last workgroup through hands the dispenser back
+    *p.ticket = 0;
+    *p.done = 0;
+  }
 }
 #undef PW_OSTEP
 #undef PW_PAIR
@@ -410,7 +437,20 @@ extern "C" int ctu_pwa_block_fwd(ctu_dtype dtype, const void* x1, const void* x2
   p.wpk = (const bf16*)w_packed; p.out = (bf16*)out;
   p.qkv1 = (bf16*)qkv1; p.qkv2 = (bf16*)qkv2; p.mr1 = mean_rstd1; p.mr2 = mean_rstd2; p.M = M; p.scale = scale;
   p.ntiles = (int)(M / PW_ROWS);
-  const size_t lds = 2 * PW_STAGE + 4 * PW_STG_WAVE + 4 * PW_C * sizeof(float);
+  const size_t lds = 2 * PW_STAGE + 4 * PW_STG_WAVE + 4 * PW_C * sizeof(float) + 16;
+  static std::atomic<unsigned> launches{0};
+  const unsigned slot = launches.fetch_add(1) & 63;
+  static unsigned* d_ticket = nullptr;
+  static unsigned* d_done = nullptr;
+  if (!d_ticket || !d_done) {
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&d_ticket), HIP_SYMBOL(g_pwa_ticket)) != hipSuccess ||
+        hipGetSymbolAddress(reinterpret_cast<void**>(&d_done), HIP_SYMBOL(g_pwa_done)) != hipSuccess) {
+      ctu_set_error("pwa_block_fwd: cannot locate the tile dispensers");
+      return CTU_ERR_ARG;
+    }
+  }
+  p.ticket = d_ticket + slot;
+  p.done = d_done + slot;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(pwa_block_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||

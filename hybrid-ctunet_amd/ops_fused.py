@@ -1465,6 +1465,7 @@ def pwa_block_ok(m, x1, x2) -> bool:
 
 
 _PWA_PACKED: Dict[int, tuple] = {}
+_PWA_STATS: Dict[tuple, torch.Tensor] = {}
 
 
 def _pwa_packed(m):
@@ -1490,7 +1491,9 @@ def pwa_block(m, x1, x2):
     M = x1.numel() // C
     if OPT["pwa1"] and C == 128 and M % 128 == 0 and not torch.is_grad_enabled():
         out = torch.empty_like(x1)
-        mr = torch.empty((2, M, 2), dtype=torch.float32, device=x1.device)
+        mr = _PWA_STATS.get((x1.device, M))     # the LayerNorm statistics nobody reads without a backward pass: one scratch per size
+        if mr is None:
+            mr = _PWA_STATS[(x1.device, M)] = torch.empty((2, M, 2), dtype=torch.float32, device=x1.device)
         L.call("ctu_pwa_block_fwd", BF16, x1.data_ptr(), x2.data_ptr(), m.norm1.weight.data_ptr(), m.norm1.bias.data_ptr(),
                m.norm2.weight.data_ptr(), m.norm2.bias.data_ptr(), _pwa_packed(m).data_ptr(), out.data_ptr(), None, None,
                mr[0].data_ptr(), mr[1].data_ptr(), M, C, float(m.scale), L.stream())

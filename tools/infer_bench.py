@@ -35,11 +35,15 @@ torch.cuda.synchronize()
 torch.cuda.reset_peak_memory_stats()
 base = torch.cuda.memory_allocated()
 reps = 3
+per_rep = []
 t0 = time.perf_counter()
 for _ in range(reps):
+    t1 = time.perf_counter()
     out = run()
-torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    per_rep.append(time.perf_counter() - t1)
 dt = (time.perf_counter() - t0) / reps
+print("passes: " + " ".join(f"{1e3 * t:.1f}" for t in per_rep) + " ms")
 peak = torch.cuda.max_memory_allocated() - base
 assert all(torch.isfinite(o).all() for o in out)
 print(f"volume {D}x{Hh}x{W}: {n_win} windows of 96^3 (overlap 0.5, gaussian blend), sw_batch_size 4")
