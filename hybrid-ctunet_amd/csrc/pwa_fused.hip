@@ -440,17 +440,23 @@ extern "C" int ctu_pwa_block_fwd(ctu_dtype dtype, const void* x1, const void* x2
   const size_t lds = 2 * PW_STAGE + 4 * PW_STG_WAVE + 4 * PW_C * sizeof(float) + 16;
   static std::atomic<unsigned> launches{0};
   const unsigned slot = launches.fetch_add(1) & 63;
-  static unsigned* d_ticket = nullptr;
-  static unsigned* d_done = nullptr;
-  if (!d_ticket || !d_done) {
-    if (hipGetSymbolAddress(reinterpret_cast<void**>(&d_ticket), HIP_SYMBOL(g_pwa_ticket)) != hipSuccess ||
-        hipGetSymbolAddress(reinterpret_cast<void**>(&d_done), HIP_SYMBOL(g_pwa_done)) != hipSuccess) {
+  // (the counters' device addresses are looked up once per device: hipGetSymbolAddress per launch made inference passes erratic)
+  static unsigned* d_ticket[16] = {};
+  static unsigned* d_done[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+    ctu_set_error("pwa_block_fwd: device ordinal out of range");
+    return CTU_ERR_ARG;
+  }
+  if (!d_ticket[dev] || !d_done[dev]) {
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&d_ticket[dev]), HIP_SYMBOL(g_pwa_ticket)) != hipSuccess ||
+        hipGetSymbolAddress(reinterpret_cast<void**>(&d_done[dev]), HIP_SYMBOL(g_pwa_done)) != hipSuccess) {
       ctu_set_error("pwa_block_fwd: cannot locate the tile dispensers");
       return CTU_ERR_ARG;
     }
   }
-  p.ticket = d_ticket + slot;
-  p.done = d_done + slot;
+  p.ticket = d_ticket[dev] + slot;
+  p.done = d_done[dev] + slot;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(pwa_block_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
