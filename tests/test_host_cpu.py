@@ -337,3 +337,18 @@ def test_data_parallel_release_restores_the_stream_switch():
     finally:
         ops.WGRAD_STREAM = before
         dp.flat.release()
+
+
+def test_plan_keys_separate_forward_with_and_without_autograd():
+    """A forward plan recorded under torch.no_grad() leaves out what only a backward pass reads (ops_fused.FFRes.save, the fused
+    cross-weight forward): the autograd mode therefore has to be part of every plan key."""
+    import torch
+    from hybrid_ctunet_amd import ops_fused as F
+    on = F._flags()
+    with torch.no_grad():
+        off = F._flags()
+    assert on != off and on[:-1] == off[:-1] and on[-1] is True and off[-1] is False
+    with torch.no_grad():
+        ff = F.FFRes("f", 512, 128, 512)
+    assert ff.fused_fwd and not ff.save
+    assert F.FFRes("f", 512, 128, 512).save
